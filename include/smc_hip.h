@@ -1,0 +1,115 @@
+/*
+ * smc_hip.h -- C ABI of libsmchip.so: the MI355X (gfx950) particle-filter hot path.
+ *
+ * Drop-in boundary for charlesknipp/sequential_monte_carlo (reference @ v1).  The reference has
+ * no FFI: its filters call Julia model methods per particle (src/particles.jl:97-98,123-124).
+ * A GPU cannot call Julia closures, so the boundary is "enumerated model family + parameter
+ * rows"; a Julia wrapper adds methods of the SAME generic functions for these model types and
+ * `ccall`s the entry points below (INTEGRATION.md shows the stub).  Each entry point names the
+ * reference function it replaces.
+ *
+ * Conventions: plain pointers and sizes only.  Host arrays are caller-owned and borrowed for
+ * the duration of the call; device state is owned by the opaque handle.  Every function
+ * returns 0 on success, a negative SMC_E* code otherwise; smc_last_error() returns a
+ * thread-local message.  Never aborts.  Indices are 0-based int32 (the Julia wrapper adds 1).
+ * Layouts: params [n_theta][n_raw] row-major; x [d][n_theta][n_x]; w, anc [n_theta][n_x].
+ * A handle is used from one host thread at a time; different handles are independent.
+ */
+#ifndef SMC_HIP_H
+#define SMC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* model families (src/state_space_models.jl) */
+#define SMC_MODEL_LG1D 1   /* UnivariateLinearGaussian :74-109  raw = (A,B,Q,R,x0,sigma0), Q R sigma0 variances */
+#define SMC_MODEL_SV1D 2   /* stochastic volatility (SURVEY A7') raw = (mu,rho,sigma)                            */
+#define SMC_MODEL_UCSV3D 3 /* UCSV :215-263                     raw = (gamma_eps,gamma_eta,x0,log_s_eps0,log_s_eta0) */
+
+#define SMC_OK 0
+#define SMC_EINVAL (-1)
+#define SMC_EHIP (-2)
+#define SMC_ESTATE (-3)
+#define SMC_ENOMEM (-4)
+
+/* flags of smc_create */
+#define SMC_FLAG_ANCESTORS 1u /* keep the ancestor vector `a` of the last step (particles.jl:117)      */
+#define SMC_FLAG_NO_RESIDENT 2u /* never use the LDS-resident whole-series kernel (testing)            */
+
+typedef struct smc_filter_s* smc_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* n_theta independent bootstrap filters of n_x particles each (the batched callers
+ * src/smc_samplers.jl:112-121,223-229,289-295,325-335 become ONE handle with n_theta > 1).
+ * seg: particles per segment (power of two in [256,8192]); 0 = automatic. It is part of the
+ * random-number contract like the seed.  Filter m uses Philox stream id m until
+ * smc_set_streams says otherwise. */
+int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, uint64_t seed, int device, uint32_t flags,
+               smc_handle* out);
+int smc_destroy(smc_handle h);
+
+/* smc.model(theta[m]) for every m (src/smc_samplers.jl:120,178,227,293,330): raw parameter rows. */
+int smc_set_params(smc_handle h, const double* raw /*[n_theta][n_raw]*/);
+/* Philox stream id per filter (e.g. the GLOBAL theta index when theta is sharded over GPUs). */
+int smc_set_streams(smc_handle h, const uint32_t* stream /*[n_theta]*/);
+int smc_reseed(smc_handle h, uint64_t seed);
+
+/* ---- the hot path ----------------------------------------------------------------------------*/
+/* bootstrap_filter(N, y, model) -> (x, w, logmu)            src/particles.jl:87-105 */
+int smc_init(smc_handle h, double y1, double* logmu /*[n_theta]*/);
+/* bootstrap_filter!(x, w, y, model) -> (logmu, w, ess)      src/particles.jl:107-129 */
+int smc_step(smc_handle h, double y_t, double* logmu /*[n_theta]*/, double* ess /*[n_theta] or NULL*/);
+/* log_likelihood(N, y, model) -> (x, w, logZ)               src/particles.jl:132-147
+ * logmu_trace / ess_trace: [T][n_theta] or NULL. */
+int smc_log_likelihood(smc_handle h, const double* y, int64_t T, double* logZ /*[n_theta]*/,
+                       double* logmu_trace, double* ess_trace);
+/* the (x, w) the reference returns / mutates; any pointer may be NULL. w is the normalised
+ * weight vector of normalize() (particles.jl:11); anc needs SMC_FLAG_ANCESTORS. */
+int smc_get_state(smc_handle h, double* x /*[d][n_theta][n_x]*/, double* w /*[n_theta][n_x]*/,
+                  int32_t* anc /*[n_theta][n_x]*/);
+/* accumulated log-likelihood so far and ESS of the current weights */
+int smc_get_logZ(smc_handle h, double* logZ /*[n_theta]*/, double* ess /*[n_theta] or NULL*/);
+/* resample!(smc) of the OUTER sampler (src/smc_samplers.jl:74-84): filter slot m <- slot a[m]
+ * (value copy of x cloud, weights and logZ; stream ids stay with the slot). */
+int smc_permute(smc_handle h, const int32_t* a /*[n_theta]*/);
+
+/* raw fixed-point weight state (tests): C [n_theta][nseg*seg], m/S/S2hi/S2lo [n_theta][nseg] */
+int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo);
+int smc_get_geometry(smc_handle h, int* seg, int* nseg, int* d, int* resident);
+/* device time (HIP events on the handle's stream) of the last init/step/log_likelihood call */
+int smc_last_elapsed_ms(smc_handle h, double* ms);
+int smc_synchronize(smc_handle h);
+
+/* ---- stand-alone A1 / A2 ---------------------------------------------------------------------*/
+/* normalize(logw) -> (logmu, w, ess)                        src/particles.jl:5-15
+ * (also the samplers' `reweight`, src/smc_samplers.jl:232,249,265,298,338) */
+int smc_normalize(const double* logw, int64_t n, double* w, double* logmu, double* ess, int device);
+/* resample(w, N) -> N iid Categorical(w) indices, unsorted  src/particles.jl:17-19 */
+int smc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t seed, uint32_t stream, uint32_t t, int32_t* a,
+                 int device);
+
+/* ---- host-side helpers (no GPU needed) ---------------------------------------------------------*/
+/* simulate(rng, model, T) -> (x, y)                         src/state_space_models.jl:11-26 */
+int smc_simulate(int model_id, const double* raw, int64_t T, uint64_t seed, double* x /*[d][T]*/, double* y /*[T]*/);
+int smc_model_dim(int model_id);
+int smc_model_nraw(int model_id);
+int smc_auto_seg(int64_t n_x);
+int smc_device_count(void);
+/* the spec's elementary functions on the host (parity tests of the host build) */
+double smc_host_exp(double x);
+double smc_host_log(double x);
+void smc_host_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void smc_host_box_muller(const uint32_t w[4], double* z0, double* z1);
+/* the same functions evaluated on the device for n inputs (math parity tests) */
+int smc_device_math(int which /*0 exp,1 log,2 sqrt,3 box-muller z0,4 z1,5 div a/b*/, const double* a, const double* b,
+                    int64_t n, double* out, int device);
+
+const char* smc_last_error(void);
+const char* smc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+"""ctypes binding of the CPU oracle (oracle/smc_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under sequential_monte_carlo_amd/ may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+LG1D, SV1D, UCSV3D = 1, 2, 3
+
+_dp = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "smc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_exp.restype = C.c_double
+        L.orc_exp.argtypes = [C.c_double]
+        L.orc_log.restype = C.c_double
+        L.orc_log.argtypes = [C.c_double]
+        L.orc_sincos2pi.argtypes = [C.c_double, _dp, _dp]
+        L.orc_box_muller.argtypes = [_u32p, _dp, _dp]
+        L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        L.orc_simulate.argtypes = [C.c_int, _dp, C.c_int, C.c_uint64, _dp, _dp]
+        L.orc_normalize.argtypes = [_dp, C.c_int64, _dp, _dp, _dp]
+        L.orc_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, _i64p]
+        L.orc_auto_seg.argtypes = [C.c_int64]
+        L.orc_filter_create.restype = C.c_void_p
+        L.orc_filter_create.argtypes = [C.c_int, _dp, C.c_int64, C.c_int, C.c_uint64, C.c_uint32]
+        L.orc_filter_destroy.argtypes = [C.c_void_p]
+        L.orc_filter_reseed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.orc_bootstrap_filter.restype = C.c_double
+        L.orc_bootstrap_filter.argtypes = [C.c_void_p, C.c_double]
+        L.orc_bootstrap_filter_step.restype = C.c_double
+        L.orc_bootstrap_filter_step.argtypes = [C.c_void_p, C.c_double, _dp]
+        L.orc_log_likelihood.restype = C.c_double
+        L.orc_log_likelihood.argtypes = [C.c_void_p, _dp, C.c_int, _dp, _dp]
+        L.orc_filter_get_state.argtypes = [C.c_void_p, _dp, _dp, _i64p, _dp]
+        L.orc_filter_ess.restype = C.c_double
+        L.orc_filter_ess.argtypes = [C.c_void_p]
+        L.orc_filter_seg.argtypes = [C.c_void_p]
+        L.orc_filter_get_weights_raw.argtypes = [C.c_void_p, _u64p, _dp, _u64p, _u64p, _u64p]
+        L.orc_log_likelihood_batch.argtypes = [C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_uint64,
+                                               C.c_uint32, _dp, C.c_int, _dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+MODEL_DIM = {LG1D: 1, SV1D: 1, UCSV3D: 3}
+MODEL_NRAW = {LG1D: 6, SV1D: 3, UCSV3D: 5}
+
+
+def exp(x):
+    L = lib()
+    return np.array([L.orc_exp(float(v)) for v in np.atleast_1d(x)])
+
+
+def log(x):
+    L = lib()
+    return np.array([L.orc_log(float(v)) for v in np.atleast_1d(x)])
+
+
+def sincos2pi(u):
+    L = lib()
+    c, s = C.c_double(), C.c_double()
+    L.orc_sincos2pi(float(u), C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def box_muller(words):
+    w = (C.c_uint32 * 4)(*words)
+    z0, z1 = C.c_double(), C.c_double()
+    lib().orc_box_muller(w, C.byref(z0), C.byref(z1))
+    return z0.value, z1.value
+
+
+def simulate(model, raw, T, seed):
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    d = MODEL_DIM[model]
+    x = np.zeros((d, T))
+    y = np.zeros(T)
+    rc = lib().orc_simulate(model, _d(raw), T, seed, _d(x), _d(y))
+    assert rc == 0
+    return x, y
+
+
+def normalize(logw):
+    logw = np.ascontiguousarray(logw, dtype=np.float64)
+    w = np.zeros_like(logw)
+    lm, ess = C.c_double(), C.c_double()
+    rc = lib().orc_normalize(_d(logw), logw.size, _d(w), C.byref(lm), C.byref(ess))
+    assert rc == 0
+    return lm.value, w, ess.value
+
+
+def resample(w, ndraw=None, seed=0, stream=0, t=0):
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    ndraw = w.size if ndraw is None else ndraw
+    a = np.zeros(ndraw, dtype=np.int64)
+    rc = lib().orc_resample(_d(w), w.size, ndraw, seed, stream, t, a.ctypes.data_as(_i64p))
+    if rc != 0:
+        raise ValueError("orc_resample rc=%d" % rc)
+    return a
+
+
+class Filter:
+    """One bootstrap particle filter of the oracle (particles.jl:87-147)."""
+
+    def __init__(self, model, raw, n, seg=0, seed=1, stream=0):
+        self.model, self.n, self.d = model, int(n), MODEL_DIM[model]
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        assert raw.size == MODEL_NRAW[model]
+        self._h = lib().orc_filter_create(model, _d(raw), self.n, seg, seed, stream)
+        if not self._h:
+            raise ValueError("orc_filter_create failed")
+        self.seg = lib().orc_filter_seg(self._h)
+        self.nseg = (self.n + self.seg - 1) // self.seg
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_filter_destroy(self._h)
+            self._h = None
+
+    def reseed(self, seed, stream=0):
+        lib().orc_filter_reseed(self._h, seed, stream)
+
+    def bootstrap_filter(self, y):
+        return lib().orc_bootstrap_filter(self._h, float(y))
+
+    def step(self, y):
+        ess = C.c_double()
+        lm = lib().orc_bootstrap_filter_step(self._h, float(y), C.byref(ess))
+        return lm, ess.value
+
+    def ess(self):
+        return lib().orc_filter_ess(self._h)
+
+    def log_likelihood(self, y, trace=False):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if trace:
+            lm = np.zeros(y.size)
+            es = np.zeros(y.size)
+            z = lib().orc_log_likelihood(self._h, _d(y), y.size, _d(lm), _d(es))
+            return z, lm, es
+        return lib().orc_log_likelihood(self._h, _d(y), y.size, None, None)
+
+    def state(self):
+        x = np.zeros((self.d, self.n))
+        w = np.zeros(self.n)
+        a = np.zeros(self.n, dtype=np.int64)
+        logw = np.zeros(self.n)
+        lib().orc_filter_get_state(self._h, _d(x), _d(w), a.ctypes.data_as(_i64p), _d(logw))
+        return x, w, a, logw
+
+    def weights_raw(self):
+        ns = self.nseg
+        Cc = np.zeros(ns * self.seg, dtype=np.uint64)
+        m = np.zeros(ns)
+        S = np.zeros(ns, dtype=np.uint64)
+        hi = np.zeros(ns, dtype=np.uint64)
+        lo = np.zeros(ns, dtype=np.uint64)
+        lib().orc_filter_get_weights_raw(self._h, Cc.ctypes.data_as(_u64p), _d(m), S.ctypes.data_as(_u64p),
+                                         hi.ctypes.data_as(_u64p), lo.ctypes.data_as(_u64p))
+        return Cc, m, S, hi, lo
+
+
+def log_likelihood_batch(model, raw, n, y, seg=0, seed=1, stream0=0):
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    nth = raw.shape[0]
+    out = np.zeros(nth)
+    rc = lib().orc_log_likelihood_batch(model, _d(raw), nth, n, seg, seed, stream0, _d(y), y.size, _d(out))
+    assert rc == 0
+    return out

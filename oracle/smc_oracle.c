@@ -1,0 +1,655 @@
+/*
+ * smc_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, never the product path).
+ *
+ * A scalar, single-threaded, plain-C restatement of the reference's particle-filter
+ * hot path, function for function:
+ *
+ *   orc_normalize              <- normalize            src/particles.jl:5-15
+ *   orc_resample               <- resample             src/particles.jl:17-19
+ *   orc_bootstrap_filter       <- bootstrap_filter     src/particles.jl:87-105
+ *   orc_bootstrap_filter_step  <- bootstrap_filter!    src/particles.jl:107-129
+ *   orc_log_likelihood         <- log_likelihood       src/particles.jl:132-147
+ *   orc_simulate               <- simulate             src/state_space_models.jl:11-26
+ *   model methods              <- initial_dist/transition/observation
+ *                                 src/state_space_models.jl:87-109 (LG), :233-259 (UCSV)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * PARITY PIN.  The reference is Julia (no toolchain here) and its arithmetic lives in
+ * un-vendored, un-pinned Distributions.jl / StatsBase.jl / Random (Project.toml:6-13), with
+ * no tests or golden vectors: bit-level parity with Julia is unpinned by construction.
+ * This oracle is pinned instead by the reference's own exact Kalman log-likelihood
+ * (src/kalman_filter.jl:29-70, restated in oracle/kalman.py): tests/test_oracle_kalman.py
+ * checks E[exp(logZ_PF - logZ_KF)] = 1 and mean(logZ_PF) - logZ_KF within MC error.
+ *
+ * Because the reference's random stream cannot be reproduced, the *specification* of the
+ * stream and of every rounding step is defined here (DESIGN.md "Numerical specification")
+ * and the HIP kernels must reproduce THIS file bit for bit:
+ *   - RNG: Philox4x32-10, key = 64-bit seed, counter = (pair index, stream, t, slot).
+ *   - normals: Box-Muller on two 53-bit uniforms; one Philox call serves the particle
+ *     pair (2p, 2p+1): z[2p] = R cos(2 pi u2), z[2p+1] = R sin(2 pi u2).
+ *   - exp / log / sincos: the polynomial kernels below (IEEE +,-,*,/,sqrt and fma only).
+ *   - weights are carried as 2^48 fixed point (q = rint(exp(logw - m) * 2^48)) so that
+ *     every sum and every prefix sum is an exact integer: the result does not depend on
+ *     the order in which a parallel machine adds them up.
+ *   - a filter with more than `seg` particles normalises each segment of `seg` particles
+ *     against its own maximum and combines the segments through a second, integer,
+ *     table (two-level multinomial draw).  iid multinomial law as in StatsBase.sample.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; never -ffast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------------------ */
+/* constants                                                                            */
+/* ------------------------------------------------------------------------------------ */
+#define ORC_LG1D 1
+#define ORC_SV1D 2
+#define ORC_UCSV3D 3
+
+#define FIX_BITS 48            /* q = rint(w~ * 2^48), w~ in [0,1] relative to segment max */
+#define MAX_SEG 8192
+#define SIM_STREAM 0xFFFFFFFFu /* stream id reserved for simulate()                       */
+#define SLOT_RESAMPLE 0u
+#define SLOT_NORMAL0 1u        /* slots 1..d : state normals                              */
+#define SLOT_OBS 8u            /* simulate(): observation noise                           */
+
+static const double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
+static const double INV_LN2 = 0x1.71547652b82fep+0;
+static const double LN2_HI = 0x1.62e42fee00000p-1;
+static const double LN2_LO = 0x1.a39ef35793c76p-33;
+static const double SQRT2 = 0x1.6a09e667f3bcdp+0;
+static const double PIO4 = 0x1.921fb54442d18p-1;
+static const double RND_MAGIC = 0x1.8p52;
+static const double TWO_M53 = 0x1p-53;
+static const double TWO_M48 = 0x1p-48;
+static const double TWO_P48 = 0x1p+48;
+static const double TWO_M96 = 0x1p-96;
+static const double TWO_P64 = 0x1p+64;
+
+/* ------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11), the counter-based generator of the spec         */
+/* ------------------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void draw(uint64_t seed, uint32_t pair, uint32_t stream, uint32_t t, uint32_t slot,
+                 uint32_t out[4]) {
+    uint32_t ctr[4] = {pair, stream, t, slot};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    orc_philox4x32_10(ctr, key, out);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* elementary functions of the spec                                                     */
+/* ------------------------------------------------------------------------------------ */
+static double bits2d(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+static uint64_t d2bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
+
+/* round to nearest-even integer: signed |v| < 2^51; and v >= 0 of any size (== rint) */
+static double rne(double v) { return (v + RND_MAGIC) - RND_MAGIC; }
+static double rne_pos(double v) { return v < 0x1p52 ? (v + 0x1p52) - 0x1p52 : v; }
+
+double orc_exp(double x) {
+    if (x != x) return x;
+    if (!(x > -708.0)) return 0.0;
+    if (x > 709.0) return INFINITY;
+    double k = rne(x * INV_LN2);
+    double r = fma(-k, LN2_HI, x);
+    r = fma(-k, LN2_LO, r);
+    double p = 0x1.6124613a86d09p-33;            /* 1/13! */
+    p = fma(p, r, 0x1.1eed8eff8d898p-29);        /* 1/12! */
+    p = fma(p, r, 0x1.ae64567f544e4p-26);
+    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = fma(p, r, 0x1.71de3a556c734p-19);
+    p = fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = fma(p, r, 0x1.1111111111111p-7);
+    p = fma(p, r, 0x1.5555555555555p-5);
+    p = fma(p, r, 0x1.5555555555555p-3);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    int64_t ki = (int64_t)k;
+    return p * bits2d((uint64_t)(ki + 1023) << 52);
+}
+
+double orc_log(double x) {
+    if (x != x || x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    int64_t e = 0;
+    if (x < 0x1p-1022) { x *= 0x1p54; e = -54; }
+    uint64_t b = d2bits(x);
+    e += (int64_t)((b >> 52) & 0x7ff) - 1023;
+    double m = bits2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > SQRT2) { m *= 0.5; e += 1; }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double R = 0x1.642c8590b2164p-4;             /* 2/23 */
+    R = fma(R, z, 0x1.8618618618618p-4);         /* 2/21 */
+    R = fma(R, z, 0x1.af286bca1af28p-4);
+    R = fma(R, z, 0x1.e1e1e1e1e1e1ep-4);
+    R = fma(R, z, 0x1.1111111111111p-3);
+    R = fma(R, z, 0x1.3b13b13b13b14p-3);
+    R = fma(R, z, 0x1.745d1745d1746p-3);
+    R = fma(R, z, 0x1.c71c71c71c71cp-3);
+    R = fma(R, z, 0x1.2492492492492p-2);
+    R = fma(R, z, 0x1.999999999999ap-2);
+    R = fma(R, z, 0x1.5555555555555p-1);         /* 2/3 */
+    R = R * z;                                   /* log(1+f) = 2s + s*R = f - s*(f - R) */
+    double dk = (double)e;
+    return dk * LN2_HI - ((s * (f - R) - dk * LN2_LO) - f);
+}
+
+/* cos and sin of 2*pi*u, u in [0,1) a multiple of 2^-53 */
+void orc_sincos2pi(double u, double* c, double* s) {
+    double a = 8.0 * u;
+    int oct = (int)a;
+    double g = a - (double)oct;
+    if (oct & 1) g = 1.0 - g;
+    double y = g * PIO4;
+    double z = y * y;
+    double ps = 0x1.952c77030ad4ap-49;           /* 1/17! */
+    ps = fma(ps, z, -0x1.ae7f3e733b81fp-41);
+    ps = fma(ps, z, 0x1.6124613a86d09p-33);
+    ps = fma(ps, z, -0x1.ae64567f544e4p-26);
+    ps = fma(ps, z, 0x1.71de3a556c734p-19);
+    ps = fma(ps, z, -0x1.a01a01a01a01ap-13);
+    ps = fma(ps, z, 0x1.1111111111111p-7);
+    ps = fma(ps, z, -0x1.5555555555555p-3);
+    double sy = fma(y * z, ps, y);
+    double pc = -0x1.6827863b97d97p-53;          /* -1/18! */
+    pc = fma(pc, z, 0x1.ae7f3e733b81fp-45);
+    pc = fma(pc, z, -0x1.93974a8c07c9dp-37);
+    pc = fma(pc, z, 0x1.1eed8eff8d898p-29);
+    pc = fma(pc, z, -0x1.27e4fb7789f5cp-22);
+    pc = fma(pc, z, 0x1.a01a01a01a01ap-16);
+    pc = fma(pc, z, -0x1.6c16c16c16c17p-10);
+    pc = fma(pc, z, 0x1.5555555555555p-5);
+    pc = fma(pc, z, -0.5);
+    double cy = fma(z, pc, 1.0);
+    int swap = (oct + 1) & 2;
+    double cc = swap ? sy : cy;
+    double ss = swap ? cy : sy;
+    if ((oct + 2) & 4) cc = -cc;
+    if (oct & 4) ss = -ss;
+    *c = cc;
+    *s = ss;
+}
+
+/* four Philox words -> two independent N(0,1) */
+void orc_box_muller(const uint32_t w[4], double* z0, double* z1) {
+    uint64_t n1 = (((uint64_t)w[1] << 32) | w[0]) >> 11;
+    uint64_t n2 = (((uint64_t)w[3] << 32) | w[2]) >> 11;
+    double u1 = (double)(n1 + 1) * TWO_M53;      /* (0,1] */
+    double u2 = (double)n2 * TWO_M53;            /* [0,1) */
+    double r = sqrt(-2.0 * orc_log(u1));
+    double c, s;
+    orc_sincos2pi(u2, &c, &s);
+    *z0 = r * c;
+    *z1 = r * s;
+}
+
+/* normals of the particle pair (2p, 2p+1) at (stream,t,slot): z[0] -> 2p, z[1] -> 2p+1 */
+static void normal_pair(uint64_t seed, int64_t p, uint32_t stream, uint32_t t, uint32_t slot, double z[2]) {
+    uint32_t w[4];
+    draw(seed, (uint32_t)p, stream, t, slot, w);
+    orc_box_muller(w, &z[0], &z[1]);
+}
+
+/* 64 resampling bits of each member of the pair */
+static void resample_pair(uint64_t seed, int64_t p, uint32_t stream, uint32_t t, uint64_t r[2]) {
+    uint32_t w[4];
+    draw(seed, (uint32_t)p, stream, t, SLOT_RESAMPLE, w);
+    r[0] = ((uint64_t)w[1] << 32) | w[0];
+    r[1] = ((uint64_t)w[3] << 32) | w[2];
+}
+
+static double u128_to_double(uint64_t hi, uint64_t lo) { return (double)hi * TWO_P64 + (double)lo; }
+
+static int ceil_log2(int64_t n) { int k = 0; while (((int64_t)1 << k) < n) ++k; return k; }
+
+/* first j in [0,n) with C[j] > T   (C non-decreasing, C[n-1] > T guaranteed by callers) */
+static int64_t upper_bound_u64(const uint64_t* C, int64_t n, uint64_t T) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (C[mid] > T) hi = mid; else lo = mid + 1;
+    }
+    return lo < n ? lo : n - 1;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* state-space models: the 4-function contract of src/state_space_models.jl:30-42       */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int id, d;
+    double raw[8];
+    double der[8];
+} orc_model;
+
+int orc_model_dim(int id) { return id == ORC_UCSV3D ? 3 : (id == ORC_LG1D || id == ORC_SV1D) ? 1 : -1; }
+int orc_model_nraw(int id) { return id == ORC_LG1D ? 6 : id == ORC_SV1D ? 3 : id == ORC_UCSV3D ? 5 : -1; }
+
+/* derived constants (what Normal(mu, sqrt(Q)) etc. rebuild per particle in the reference) */
+static int model_init(orc_model* m, int id, const double* raw) {
+    m->id = id;
+    m->d = orc_model_dim(id);
+    if (m->d < 0) return -1;
+    memset(m->raw, 0, sizeof m->raw);
+    memset(m->der, 0, sizeof m->der);
+    memcpy(m->raw, raw, sizeof(double) * (size_t)orc_model_nraw(id));
+    if (id == ORC_LG1D) {
+        /* raw = (A,B,Q,R,x0,sigma0), Q R sigma0 are VARIANCES: ssm.jl:93,102,108 */
+        double sR = sqrt(raw[3]);
+        m->der[0] = sqrt(raw[2]);                 /* sQ  */
+        m->der[1] = sR;
+        m->der[2] = sqrt(raw[5]);                 /* s0  */
+        m->der[3] = 1.0 / sR;
+        m->der[4] = -HALF_LOG2PI - orc_log(sR);   /* logpdf constant */
+    } else if (id == ORC_SV1D) {
+        /* raw = (mu, rho, sigma): x1 ~ N(mu, sigma^2/(1-rho^2)) */
+        m->der[0] = raw[2] / sqrt(1.0 - raw[1] * raw[1]);
+    }
+    return 0;
+}
+
+/* rand(initial_dist(model)) : ssm.jl:105-109, :249-259 */
+static void model_initial(const orc_model* m, const double* z, double* x) {
+    switch (m->id) {
+    case ORC_LG1D: x[0] = fma(m->der[2], z[0], m->raw[4]); break;
+    case ORC_SV1D: x[0] = fma(m->der[0], z[0], m->raw[0]); break;
+    case ORC_UCSV3D:
+        /* raw = (gamma_eps, gamma_eta, x0, lse0, lsn0); gamma is a STD-DEV: ssm.jl:239-240 */
+        x[0] = fma(orc_exp(0.5 * m->raw[3]), z[0], m->raw[2]);
+        x[1] = fma(m->raw[0], z[1], m->raw[3]);
+        x[2] = fma(m->raw[1], z[2], m->raw[4]);
+        break;
+    }
+}
+
+/* rand(transition(model, xp)) : ssm.jl:87-94, :233-242 (x' uses the PREVIOUS log-vol) */
+static void model_transition(const orc_model* m, const double* xp, const double* z, double* x) {
+    switch (m->id) {
+    case ORC_LG1D: x[0] = fma(m->der[0], z[0], m->raw[0] * xp[0]); break;
+    case ORC_SV1D: x[0] = fma(m->raw[2], z[0], fma(m->raw[1], xp[0] - m->raw[0], m->raw[0])); break;
+    case ORC_UCSV3D:
+        x[0] = fma(orc_exp(0.5 * xp[1]), z[0], xp[0]);
+        x[1] = fma(m->raw[0], z[1], xp[1]);
+        x[2] = fma(m->raw[1], z[2], xp[2]);
+        break;
+    }
+}
+
+/* logpdf(observation(model, x), y) : ssm.jl:96-103, :244-247; Normal logpdf =
+ * -(z^2 + log 2pi)/2 - log(sigma), z = (y - mean)/sigma */
+static double model_logobs(const orc_model* m, const double* x, double y) {
+    double z, c;
+    switch (m->id) {
+    case ORC_LG1D:
+        z = (y - m->raw[1] * x[0]) * m->der[3];
+        c = m->der[4];
+        break;
+    case ORC_SV1D:
+        z = y * orc_exp(-0.5 * x[0]);
+        c = fma(-0.5, x[0], -HALF_LOG2PI);
+        break;
+    default:
+        z = (y - x[0]) * orc_exp(-0.5 * x[2]);
+        c = fma(-0.5, x[2], -HALF_LOG2PI);
+        break;
+    }
+    return fma(-0.5 * z, z, c);
+}
+
+/* mean and sd of the observation density (simulate only) */
+static void model_obs_moments(const orc_model* m, const double* x, double* mean, double* sd) {
+    switch (m->id) {
+    case ORC_LG1D: *mean = m->raw[1] * x[0]; *sd = m->der[1]; break;
+    case ORC_SV1D: *mean = 0.0; *sd = orc_exp(0.5 * x[0]); break;
+    default: *mean = x[0]; *sd = orc_exp(0.5 * x[2]); break;
+    }
+}
+
+/* simulate(rng, model, T) : ssm.jl:11-26.  x is [d][T]. */
+int orc_simulate(int id, const double* raw, int T, uint64_t seed, double* x, double* y) {
+    orc_model m;
+    if (model_init(&m, id, raw)) return -1;
+    double xc[3], xn[3], z[3], mean, sd;
+    for (int t = 0; t < T; ++t) {
+        double zp[2];
+        for (int k = 0; k < m.d; ++k) { normal_pair(seed, 0, SIM_STREAM, (uint32_t)t, SLOT_NORMAL0 + (uint32_t)k, zp); z[k] = zp[0]; }
+        if (t == 0) model_initial(&m, z, xn); else model_transition(&m, xc, z, xn);
+        model_obs_moments(&m, xn, &mean, &sd);
+        normal_pair(seed, 0, SIM_STREAM, (uint32_t)t, SLOT_OBS, zp);
+        y[t] = fma(sd, zp[0], mean);
+        for (int k = 0; k < m.d; ++k) { xc[k] = xn[k]; x[(size_t)k * T + t] = xn[k]; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* A1/A2 stand-alone: normalize(logw) and resample(w, N)    particles.jl:5-19            */
+/* (single level; used for the outer theta-level `reweight`/`resample`)                  */
+/* ------------------------------------------------------------------------------------ */
+static int fix_bits_for(int64_t n) { int k = 62 - ceil_log2(n); return k > FIX_BITS ? FIX_BITS : k; }
+
+static uint64_t to_fix(double wrel, double scale) { return (uint64_t)rne_pos(wrel * scale); }
+
+int orc_normalize(const double* logw, int64_t n, double* w, double* logmu, double* ess) {
+    if (n <= 0) return -1;
+    double maxw = -INFINITY;                                     /* maxw = maximum(logw)     */
+    for (int64_t i = 0; i < n; ++i) if (logw[i] > maxw) maxw = logw[i];
+    int K = fix_bits_for(n);
+    double scale = bits2d((uint64_t)(K + 1023) << 52);
+    uint64_t S = 0; u128 S2 = 0;
+    uint64_t* q = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) {                            /* w = exp.(logw .- maxw)   */
+        double e = (logw[i] == logw[i] && maxw > -INFINITY) ? orc_exp(logw[i] - maxw) : 0.0;
+        q[i] = to_fix(e, scale);
+        S += q[i];                                               /* sumw = sum(w)            */
+        S2 += (u128)q[i] * q[i];
+    }
+    double Sd = (double)S;
+    *logmu = S ? (maxw + orc_log(Sd * bits2d((uint64_t)(1023 - K) << 52))) - orc_log((double)n)
+               : -INFINITY;                                      /* maxw+log(sumw)-log(N)    */
+    for (int64_t i = 0; i < n; ++i) w[i] = S ? (double)q[i] / Sd : 0.0;   /* w = w/sumw      */
+    *ess = S ? (Sd * Sd) / u128_to_double((uint64_t)(S2 >> 64), (uint64_t)S2) : 0.0;   /* 1/sum(w.^2) */
+    free(q);
+    return 0;
+}
+
+/* N iid draws from Categorical(w), unsorted: sample(1:n, Weights(w), N). 0-based output. */
+int orc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t seed, uint32_t stream, uint32_t t,
+                 int64_t* a) {
+    if (n <= 0) return -1;
+    double wmax = 0.0;
+    for (int64_t i = 0; i < n; ++i) if (w[i] > wmax) wmax = w[i];
+    if (!(wmax > 0.0) || wmax == INFINITY) return -2;
+    int K = fix_bits_for(n);
+    double scale = bits2d((uint64_t)(K + 1023) << 52);
+    uint64_t* C = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+    uint64_t acc = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double r = w[i] / wmax;
+        acc += (r == r && r > 0.0) ? to_fix(r, scale) : 0;
+        C[i] = acc;
+    }
+    for (int64_t i = 0; i < ndraw; ++i) {
+        uint64_t r[2];
+        resample_pair(seed, i >> 1, stream, t, r);
+        uint64_t T = (uint64_t)(((u128)r[i & 1] * acc) >> 64);
+        a[i] = upper_bound_u64(C, n, T);
+    }
+    free(C);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* the filter's weights object: segmented fixed-point normalisation                      */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t n;      /* particles                                   */
+    int seg, nseg;  /* segment length (power of two), #segments    */
+    int QK;         /* fixed-point bits of the segment table       */
+    uint64_t* C;    /* [nseg*seg] segment-local inclusive sums of q */
+    double* m;      /* [nseg] segment max of logw                   */
+    uint64_t *S, *S2hi, *S2lo;   /* [nseg] sum q, sum q^2 (128 bit) */
+    /* global combine */
+    double gmax;
+    uint64_t* Dcum; /* [nseg] inclusive sums of Q_b                 */
+    double* fd;     /* [nseg] S_b / Q_b                             */
+    uint64_t Dtot, Rtot;
+    double logmu, ess;
+} orc_weights;
+
+static void weights_alloc(orc_weights* W, int64_t n, int seg) {
+    W->n = n; W->seg = seg; W->nseg = (int)((n + seg - 1) / seg);
+    int shn = ceil_log2(W->nseg);
+    W->QK = 49 - shn;
+    size_t ns = (size_t)W->nseg;
+    W->C = (uint64_t*)calloc(ns * (size_t)seg, 8);
+    W->m = (double*)calloc(ns, 8);
+    W->S = (uint64_t*)calloc(ns, 8);
+    W->S2hi = (uint64_t*)calloc(ns, 8);
+    W->S2lo = (uint64_t*)calloc(ns, 8);
+    W->Dcum = (uint64_t*)calloc(ns, 8);
+    W->fd = (double*)calloc(ns, 8);
+}
+static void weights_free(orc_weights* W) {
+    free(W->C); free(W->m); free(W->S); free(W->S2hi); free(W->S2lo); free(W->Dcum); free(W->fd);
+}
+
+/* normalize(logw) of particles.jl:5-15, segment by segment, then the integer combine */
+static void weights_normalize(orc_weights* W, const double* logw) {
+    const int seg = W->seg;
+    for (int b = 0; b < W->nseg; ++b) {
+        int64_t i0 = (int64_t)b * seg, i1 = i0 + seg < W->n ? i0 + seg : W->n;
+        double mb = -INFINITY;
+        for (int64_t i = i0; i < i1; ++i) if (logw[i] > mb) mb = logw[i];   /* NaN never wins */
+        uint64_t acc = 0; u128 acc2 = 0;
+        for (int64_t i = i0; i < i0 + seg; ++i) {
+            uint64_t q = 0;
+            if (i < i1 && logw[i] == logw[i] && mb > -INFINITY) q = to_fix(orc_exp(logw[i] - mb), TWO_P48);
+            acc += q; acc2 += (u128)q * q;
+            W->C[i] = acc;
+        }
+        W->m[b] = mb; W->S[b] = acc; W->S2hi[b] = (uint64_t)(acc2 >> 64); W->S2lo[b] = (uint64_t)acc2;
+    }
+    /* combine: what the next step's kernel prologue (or the finalize kernel) computes */
+    double g = -INFINITY;
+    for (int b = 0; b < W->nseg; ++b) if (W->m[b] > g) g = W->m[b];
+    W->gmax = g;
+    double qscale = bits2d((uint64_t)(W->QK + 1023) << 52);
+    uint64_t D = 0, R = 0;
+    for (int b = 0; b < W->nseg; ++b) {
+        double e = (g > -INFINITY) ? orc_exp(W->m[b] - g) : 0.0;
+        double sw = (double)W->S[b] * TWO_M48;
+        double sw2 = u128_to_double(W->S2hi[b], W->S2lo[b]) * TWO_M96;
+        uint64_t Qb = (uint64_t)rne_pos(sw * e * qscale);
+        uint64_t Rb = (uint64_t)rne_pos(sw2 * e * e * qscale);
+        D += Qb; R += Rb;
+        W->Dcum[b] = D;
+        W->fd[b] = Qb ? (double)W->S[b] / (double)Qb : 0.0;
+    }
+    W->Dtot = D; W->Rtot = R;
+    double inv = bits2d((uint64_t)(1023 - W->QK) << 52);
+    double Dd = (double)D * inv, Rd = (double)R * inv;
+    W->logmu = D ? (g + orc_log(Dd)) - orc_log((double)W->n) : -INFINITY;
+    W->ess = R ? Dd * Dd / Rd : 0.0;
+}
+
+/* ancestor of particle i: one 64-bit draw, two-level inverse CDF */
+static int64_t weights_draw(const orc_weights* W, uint64_t r, int64_t i) {
+    if (W->Dtot == 0) return i;                                  /* collapsed filter: identity */
+    if (W->nseg == 1) {
+        uint64_t T2 = (uint64_t)(((u128)r * W->S[0]) >> 64);
+        return upper_bound_u64(W->C, W->seg, T2);
+    }
+    u128 P = (u128)r * W->Dtot;
+    uint64_t T1 = (uint64_t)(P >> 64), lo = (uint64_t)P;
+    int64_t b = upper_bound_u64(W->Dcum, W->nseg, T1);
+    uint64_t rho = T1 - (b ? W->Dcum[b - 1] : 0);
+    double pos = ((double)rho + (double)(lo >> 11) * TWO_M53) * W->fd[b];
+    uint64_t T2 = (uint64_t)pos;
+    if (T2 > W->S[b] - 1) T2 = W->S[b] - 1;
+    return b * W->seg + upper_bound_u64(W->C + (size_t)b * W->seg, W->seg, T2);
+}
+
+/* dense normalised weights w_i (what the reference's normalize returns as `w`) */
+static void weights_dense(const orc_weights* W, double* w) {
+    double inv = bits2d((uint64_t)(1023 - W->QK) << 52);
+    double Dd = (double)W->Dtot * inv;
+    for (int b = 0; b < W->nseg; ++b) {
+        double e = (W->gmax > -INFINITY) ? orc_exp(W->m[b] - W->gmax) : 0.0;
+        for (int j = 0; j < W->seg; ++j) {
+            int64_t i = (int64_t)b * W->seg + j;
+            if (i >= W->n) break;
+            uint64_t q = W->C[i] - (j ? W->C[i - 1] : 0);
+            w[i] = W->Dtot ? ((double)q * TWO_M48) * e / Dd : 0.0;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* the filter                                                                            */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    orc_model model;
+    int64_t n;
+    uint64_t seed;
+    uint32_t stream, t;     /* t = index of the NEXT observation (0 before bootstrap_filter) */
+    double *x, *xp, *logw;  /* x is [d][n] */
+    int64_t* a;
+    orc_weights W;
+} orc_filter;
+
+int orc_auto_seg(int64_t n) {
+    if (n > MAX_SEG) return 2048;
+    int s = 256;
+    while (s < n) s <<= 1;
+    return s;
+}
+
+orc_filter* orc_filter_create(int model, const double* raw, int64_t n, int seg, uint64_t seed, uint32_t stream) {
+    if (n <= 0) return NULL;
+    if (seg == 0) seg = orc_auto_seg(n);
+    if (seg < 2 || seg > MAX_SEG || (seg & (seg - 1))) return NULL;
+    orc_filter* f = (orc_filter*)calloc(1, sizeof *f);
+    if (model_init(&f->model, model, raw)) { free(f); return NULL; }
+    f->n = n; f->seed = seed; f->stream = stream; f->t = 0;
+    size_t d = (size_t)f->model.d;
+    f->x = (double*)calloc(d * (size_t)n, 8);
+    f->xp = (double*)calloc(d * (size_t)n, 8);
+    f->logw = (double*)calloc((size_t)n, 8);
+    f->a = (int64_t*)calloc((size_t)n, 8);
+    weights_alloc(&f->W, n, seg);
+    return f;
+}
+
+void orc_filter_destroy(orc_filter* f) {
+    if (!f) return;
+    free(f->x); free(f->xp); free(f->logw); free(f->a);
+    weights_free(&f->W);
+    free(f);
+}
+
+void orc_filter_reseed(orc_filter* f, uint64_t seed, uint32_t stream) { f->seed = seed; f->stream = stream; f->t = 0; }
+
+/* bootstrap_filter(N, y, model)  particles.jl:87-105  -> logmu */
+double orc_bootstrap_filter(orc_filter* f, double y) {
+    const int d = f->model.d;
+    const int64_t n = f->n;
+    double z[3], xi[3], zp[3][2];
+    for (int64_t i = 0; i < n; ++i) {
+        if (!(i & 1)) for (int k = 0; k < d; ++k) normal_pair(f->seed, i >> 1, f->stream, 0, SLOT_NORMAL0 + (uint32_t)k, zp[k]);
+        for (int k = 0; k < d; ++k) z[k] = zp[k][i & 1];
+        model_initial(&f->model, z, xi);                        /* x[i] = rand(initial_dist)        */
+        for (int k = 0; k < d; ++k) f->x[(size_t)k * n + i] = xi[k];
+        f->logw[i] = model_logobs(&f->model, xi, y);            /* logw[i] = logpdf(observation, y) */
+        f->a[i] = i;
+    }
+    weights_normalize(&f->W, f->logw);                          /* logmu,w,_ = normalize(logw)      */
+    f->t = 1;
+    return f->W.logmu;
+}
+
+/* bootstrap_filter!(x, w, y, model)  particles.jl:107-129  -> (logmu, ess) */
+double orc_bootstrap_filter_step(orc_filter* f, double y, double* ess) {
+    const int d = f->model.d;
+    const int64_t n = f->n;
+    double z[3], xpi[3], xi[3], zp[3][2];
+    uint64_t r[2];
+    for (int64_t i = 0; i < n; ++i) {                           /* a = resample(weights)            */
+        if (!(i & 1)) resample_pair(f->seed, i >> 1, f->stream, f->t, r);
+        f->a[i] = weights_draw(&f->W, r[i & 1], i);
+    }
+    for (int k = 0; k < d; ++k)                                 /* xp = deepcopy(x[a])              */
+        for (int64_t i = 0; i < n; ++i) f->xp[(size_t)k * n + i] = f->x[(size_t)k * n + f->a[i]];
+    for (int64_t i = 0; i < n; ++i) {
+        if (!(i & 1)) for (int k = 0; k < d; ++k) normal_pair(f->seed, i >> 1, f->stream, f->t, SLOT_NORMAL0 + (uint32_t)k, zp[k]);
+        for (int k = 0; k < d; ++k) {
+            z[k] = zp[k][i & 1];
+            xpi[k] = f->xp[(size_t)k * n + i];
+        }
+        model_transition(&f->model, xpi, z, xi);                /* x[i] = rand(transition(xp[i]))   */
+        for (int k = 0; k < d; ++k) f->x[(size_t)k * n + i] = xi[k];
+        f->logw[i] = model_logobs(&f->model, xi, y);            /* logw[i] = logpdf(observation, y) */
+    }
+    weights_normalize(&f->W, f->logw);                          /* return normalize(logw)           */
+    f->t += 1;
+    if (ess) *ess = f->W.ess;
+    return f->W.logmu;
+}
+
+/* log_likelihood(N, y, model)  particles.jl:132-147 -> logZ ; traces optional */
+double orc_log_likelihood(orc_filter* f, const double* y, int T, double* logmu_trace, double* ess_trace) {
+    double logZ = orc_bootstrap_filter(f, y[0]);
+    if (logmu_trace) logmu_trace[0] = logZ;
+    if (ess_trace) ess_trace[0] = f->W.ess;
+    for (int t = 1; t < T; ++t) {
+        double ess, logmu = orc_bootstrap_filter_step(f, y[t], &ess);
+        logZ += logmu;
+        if (logmu_trace) logmu_trace[t] = logmu;
+        if (ess_trace) ess_trace[t] = ess;
+    }
+    return logZ;
+}
+
+/* x [d][n], normalised w [n], last ancestors a [n] (0-based), logw [n]; any pointer may be NULL */
+void orc_filter_get_state(const orc_filter* f, double* x, double* w, int64_t* a, double* logw) {
+    if (x) memcpy(x, f->x, sizeof(double) * (size_t)f->model.d * (size_t)f->n);
+    if (w) weights_dense(&f->W, w);
+    if (a) memcpy(a, f->a, sizeof(int64_t) * (size_t)f->n);
+    if (logw) memcpy(logw, f->logw, sizeof(double) * (size_t)f->n);
+}
+
+double orc_filter_ess(const orc_filter* f) { return f->W.ess; }
+int orc_filter_seg(const orc_filter* f) { return f->W.seg; }
+
+/* raw internal weights state, for kernel-level parity tests: C [nseg*seg], m/S/S2hi/S2lo [nseg] */
+void orc_filter_get_weights_raw(const orc_filter* f, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi,
+                                uint64_t* S2lo) {
+    size_t ns = (size_t)f->W.nseg;
+    if (C) memcpy(C, f->W.C, 8 * ns * (size_t)f->W.seg);
+    if (m) memcpy(m, f->W.m, 8 * ns);
+    if (S) memcpy(S, f->W.S, 8 * ns);
+    if (S2hi) memcpy(S2hi, f->W.S2hi, 8 * ns);
+    if (S2lo) memcpy(S2lo, f->W.S2lo, 8 * ns);
+}
+
+/* batched A8 convenience: n_theta independent filters, stream = stream0 + m. logZ [n_theta]. */
+int orc_log_likelihood_batch(int model, const double* raw /*[n_theta][nraw]*/, int n_theta, int64_t n, int seg,
+                             uint64_t seed, uint32_t stream0, const double* y, int T, double* logZ) {
+    int nraw = orc_model_nraw(model);
+    if (nraw < 0) return -1;
+    for (int m = 0; m < n_theta; ++m) {
+        orc_filter* f = orc_filter_create(model, raw + (size_t)m * nraw, n, seg, seed, stream0 + (uint32_t)m);
+        if (!f) return -2;
+        logZ[m] = orc_log_likelihood(f, y, T, NULL, NULL);
+        orc_filter_destroy(f);
+    }
+    return 0;
+}

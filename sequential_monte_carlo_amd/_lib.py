@@ -1,0 +1,228 @@
+"""ctypes binding of libsmchip.so (C ABI: include/smc_hip.h).
+
+The HIP extension is the product: if it is missing or cannot be loaded this module raises.
+There is no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsmchip.so")
+
+MODEL_LG1D, MODEL_SV1D, MODEL_UCSV3D = 1, 2, 3
+FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
+
+# every symbol include/smc_hip.h declares
+EXPORTS = [
+    "smc_create", "smc_destroy", "smc_set_params", "smc_set_streams", "smc_reseed", "smc_init", "smc_step",
+    "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_get_weights_raw", "smc_get_geometry",
+    "smc_last_elapsed_ms", "smc_synchronize", "smc_normalize", "smc_resample", "smc_simulate", "smc_model_dim",
+    "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
+    "smc_host_box_muller", "smc_device_math", "smc_last_error", "smc_version",
+]
+
+_dp = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_ip = C.POINTER(C.c_int)
+
+
+class SmcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libsmchip.so (built by `__graft_entry__.build()` / csrc/Makefile). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmcError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    h = C.c_void_p
+    L.smc_create.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(h)]
+    L.smc_destroy.argtypes = [h]
+    L.smc_set_params.argtypes = [h, _dp]
+    L.smc_set_streams.argtypes = [h, _u32p]
+    L.smc_reseed.argtypes = [h, C.c_uint64]
+    L.smc_init.argtypes = [h, C.c_double, _dp]
+    L.smc_step.argtypes = [h, C.c_double, _dp, _dp]
+    L.smc_log_likelihood.argtypes = [h, _dp, C.c_int64, _dp, _dp, _dp]
+    L.smc_get_state.argtypes = [h, _dp, _dp, _i32p]
+    L.smc_get_logZ.argtypes = [h, _dp, _dp]
+    L.smc_permute.argtypes = [h, _i32p]
+    L.smc_get_weights_raw.argtypes = [h, _u64p, _dp, _u64p, _u64p, _u64p]
+    L.smc_get_geometry.argtypes = [h, _ip, _ip, _ip, _ip]
+    L.smc_last_elapsed_ms.argtypes = [h, _dp]
+    L.smc_synchronize.argtypes = [h]
+    L.smc_normalize.argtypes = [_dp, C.c_int64, _dp, _dp, _dp, C.c_int]
+    L.smc_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, _i32p, C.c_int]
+    L.smc_simulate.argtypes = [C.c_int, _dp, C.c_int64, C.c_uint64, _dp, _dp]
+    L.smc_model_dim.argtypes = [C.c_int]
+    L.smc_model_nraw.argtypes = [C.c_int]
+    L.smc_auto_seg.argtypes = [C.c_int64]
+    L.smc_host_exp.restype = C.c_double
+    L.smc_host_exp.argtypes = [C.c_double]
+    L.smc_host_log.restype = C.c_double
+    L.smc_host_log.argtypes = [C.c_double]
+    L.smc_host_philox4x32_10.restype = None
+    L.smc_host_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+    L.smc_host_box_muller.restype = None
+    L.smc_host_box_muller.argtypes = [_u32p, _dp, _dp]
+    L.smc_device_math.argtypes = [C.c_int, _dp, _dp, C.c_int64, _dp, C.c_int]
+    L.smc_last_error.restype = C.c_char_p
+    L.smc_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SmcError("libsmchip error %d: %s" % (rc, lib().smc_last_error().decode()))
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def device_count():
+    return lib().smc_device_count()
+
+
+def simulate(model_id, raw, T, seed):
+    """simulate(rng, model, T) -> (x [d][T], y [T])   src/state_space_models.jl:11-26 (host code)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    d = lib().smc_model_dim(model_id)
+    x = np.zeros((d, T))
+    y = np.zeros(T)
+    check(lib().smc_simulate(model_id, _d(raw), T, seed, _d(x), _d(y)))
+    return x, y
+
+
+def normalize(logw, device=0):
+    logw = np.ascontiguousarray(logw, dtype=np.float64)
+    w = np.zeros_like(logw)
+    lm, ess = C.c_double(), C.c_double()
+    check(lib().smc_normalize(_d(logw), logw.size, _d(w), C.byref(lm), C.byref(ess), device))
+    return lm.value, w, ess.value
+
+
+def resample(w, ndraw=None, seed=0, stream=0, t=0, device=0):
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    ndraw = w.size if ndraw is None else int(ndraw)
+    a = np.zeros(ndraw, dtype=np.int32)
+    check(lib().smc_resample(_d(w), w.size, ndraw, seed, stream, t, a.ctypes.data_as(_i32p), device))
+    return a
+
+
+def device_math(which, a, b=None, device=0):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64) if b is not None else None
+    out = np.zeros_like(a)
+    check(lib().smc_device_math(which, _d(a), _d(b), a.size, _d(out), device))
+    return out
+
+
+class Handle:
+    """n_theta bootstrap filters of n_x particles on one GPU (opaque smc_handle)."""
+
+    def __init__(self, model_id, n_theta, n_x, seg=0, seed=1, device=0, flags=0):
+        self._h = C.c_void_p()
+        self.model_id, self.n_theta, self.n_x = model_id, int(n_theta), int(n_x)
+        check(lib().smc_create(model_id, self.n_theta, self.n_x, seg, seed, device, flags, C.byref(self._h)))
+        seg_, nseg, d, res = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        check(lib().smc_get_geometry(self._h, C.byref(seg_), C.byref(nseg), C.byref(d), C.byref(res)))
+        self.seg, self.nseg, self.d, self.resident = seg_.value, nseg.value, d.value, bool(res.value)
+        self.flags = flags
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().smc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, raw):
+        raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(self.n_theta, -1)
+        assert raw.shape[1] == lib().smc_model_nraw(self.model_id)
+        check(lib().smc_set_params(self._h, _d(raw)))
+
+    def set_streams(self, streams):
+        s = np.ascontiguousarray(streams, dtype=np.uint32)
+        assert s.size == self.n_theta
+        check(lib().smc_set_streams(self._h, s.ctypes.data_as(_u32p)))
+
+    def reseed(self, seed):
+        check(lib().smc_reseed(self._h, seed))
+
+    def init(self, y1):
+        lm = np.zeros(self.n_theta)
+        check(lib().smc_init(self._h, float(y1), _d(lm)))
+        return lm
+
+    def step(self, y):
+        lm = np.zeros(self.n_theta)
+        ess = np.zeros(self.n_theta)
+        check(lib().smc_step(self._h, float(y), _d(lm), _d(ess)))
+        return lm, ess
+
+    def log_likelihood(self, y, trace=False):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        logZ = np.zeros(self.n_theta)
+        if trace:
+            lm = np.zeros((y.size, self.n_theta))
+            es = np.zeros((y.size, self.n_theta))
+            check(lib().smc_log_likelihood(self._h, _d(y), y.size, _d(logZ), _d(lm), _d(es)))
+            return logZ, lm, es
+        check(lib().smc_log_likelihood(self._h, _d(y), y.size, _d(logZ), None, None))
+        return logZ
+
+    def state(self, want_w=True, want_anc=None):
+        x = np.zeros((self.d, self.n_theta, self.n_x))
+        w = np.zeros((self.n_theta, self.n_x)) if want_w else None
+        if want_anc is None:
+            want_anc = bool(self.flags & FLAG_ANCESTORS)
+        a = np.zeros((self.n_theta, self.n_x), dtype=np.int32) if want_anc else None
+        check(lib().smc_get_state(self._h, _d(x), _d(w), a.ctypes.data_as(_i32p) if a is not None else None))
+        return x, w, a
+
+    def logZ(self):
+        z = np.zeros(self.n_theta)
+        e = np.zeros(self.n_theta)
+        check(lib().smc_get_logZ(self._h, _d(z), _d(e)))
+        return z, e
+
+    def permute(self, a):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        assert a.size == self.n_theta
+        check(lib().smc_permute(self._h, a.ctypes.data_as(_i32p)))
+
+    def weights_raw(self):
+        npad = self.nseg * self.seg
+        Cc = np.zeros((self.n_theta, npad), dtype=np.uint64)
+        m = np.zeros((self.n_theta, self.nseg))
+        S = np.zeros((self.n_theta, self.nseg), dtype=np.uint64)
+        hi = np.zeros_like(S)
+        lo = np.zeros_like(S)
+        check(lib().smc_get_weights_raw(self._h, Cc.ctypes.data_as(_u64p), _d(m), S.ctypes.data_as(_u64p),
+                                        hi.ctypes.data_as(_u64p), lo.ctypes.data_as(_u64p)))
+        return Cc, m, S, hi, lo
+
+    def elapsed_ms(self):
+        ms = C.c_double()
+        check(lib().smc_last_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        check(lib().smc_synchronize(self._h))

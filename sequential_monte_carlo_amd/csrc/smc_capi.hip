@@ -1,0 +1,617 @@
+// smc_capi.hip -- C ABI (include/smc_hip.h) over the gfx950 kernels in smc_kernels.h.
+// Handle-owned device state, one HIP stream per handle, HIP-event timing of every call.
+// There is NO CPU fallback: every filter entry point launches HIP kernels or fails.
+#include "../../include/smc_hip.h"
+#include "smc_kernels.h"
+#include "smc_resident.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace smc;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess)                                                                                 \
+            return fail(SMC_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +      \
+                                      std::to_string(__LINE__) + ")");                                        \
+    } while (0)
+
+struct smc_filter_s {
+    int model = 0, d = 0, device = 0;
+    uint32_t flags = 0;
+    FilterView v{};
+    Params* d_params = nullptr;
+    uint32_t* d_stream = nullptr;
+    int32_t* d_perm = nullptr;
+    double* d_logZ_tmp = nullptr;
+    double* d_y = nullptr;
+    int64_t ycap = 0;
+    double *d_tr_logmu = nullptr, *d_tr_ess = nullptr;
+    int64_t trcap = 0;
+    double* d_wdense = nullptr;
+    StepRec* d_recs = nullptr;
+    int64_t reccap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cur = 0;
+    uint32_t t = 0;        // index of the next observation
+    bool inited = false;   // weights exist
+    bool emitted = false;  // logmu/ess of the current weights already produced
+    bool have_params = false;
+    bool resident_ok = false;
+    int threads = 0, np = 0;
+    double last_ms = 0.0;
+};
+
+// ---- geometry ------------------------------------------------------------------------------
+struct Geo { int threads, np; };
+static bool geo_for_seg(int seg, Geo& g) {
+    switch (seg) {
+    case 256: g = {128, 1}; return true;
+    case 512: g = {256, 1}; return true;
+    case 1024: g = {256, 2}; return true;
+    case 2048: g = {256, 4}; return true;
+    case 4096: g = {512, 4}; return true;
+    case 8192: g = {1024, 4}; return true;
+    }
+    return false;
+}
+
+extern "C" int smc_auto_seg(int64_t n) {
+    if (n > MAX_SEG) return 2048;
+    int s = 256;
+    while (s < n) s <<= 1;
+    return s;
+}
+extern "C" int smc_model_dim(int id) { return model_dim_rt(id); }
+extern "C" int smc_model_nraw(int id) { return model_nraw_rt(id); }
+extern "C" const char* smc_last_error(void) { return g_err.c_str(); }
+extern "C" const char* smc_version(void) { return "smchip 0.1 (gfx950)"; }
+extern "C" int smc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- kernel dispatch -------------------------------------------------------------------------
+template <int MODEL, int THREADS, int NP>
+static hipError_t launch_init(smc_filter_s* h, double y) {
+    const size_t lds = scr_words(THREADS, NP) * 8;
+    hipLaunchKernelGGL((k_init<MODEL, THREADS, NP>), dim3(h->v.nseg, h->v.ntheta), dim3(THREADS), lds, h->stream, h->v,
+                       h->cur, y);
+    return hipGetLastError();
+}
+template <int MODEL, int THREADS, int NP>
+static hipError_t launch_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) {
+    const size_t lds = table_lds_bytes(h->v.nseg_p2, THREADS, NP);
+    hipLaunchKernelGGL((k_step<MODEL, THREADS, NP>), dim3(h->v.nseg, h->v.ntheta), dim3(THREADS), lds, h->stream, h->v,
+                       h->cur, t, emit_prev, y);
+    return hipGetLastError();
+}
+
+#define DISPATCH_GEO(MODEL, FN, ...)                                           \
+    switch (h->v.seg) {                                                        \
+    case 256: return FN<MODEL, 128, 1>(__VA_ARGS__);                           \
+    case 512: return FN<MODEL, 256, 1>(__VA_ARGS__);                           \
+    case 1024: return FN<MODEL, 256, 2>(__VA_ARGS__);                          \
+    case 2048: return FN<MODEL, 256, 4>(__VA_ARGS__);                          \
+    case 4096: return FN<MODEL, 512, 4>(__VA_ARGS__);                          \
+    case 8192: return FN<MODEL, 1024, 4>(__VA_ARGS__);                         \
+    }                                                                          \
+    return hipErrorInvalidValue;
+
+#define DISPATCH(FN, ...)                                                      \
+    switch (h->model) {                                                        \
+    case MODEL_LG1D: DISPATCH_GEO(MODEL_LG1D, FN, __VA_ARGS__)                 \
+    case MODEL_SV1D: DISPATCH_GEO(MODEL_SV1D, FN, __VA_ARGS__)                 \
+    case MODEL_UCSV3D: DISPATCH_GEO(MODEL_UCSV3D, FN, __VA_ARGS__)             \
+    }                                                                          \
+    return hipErrorInvalidValue;
+
+static hipError_t do_init(smc_filter_s* h, double y) { DISPATCH(launch_init, h, y) }
+static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) { DISPATCH(launch_step, h, t, emit_prev, y) }
+
+static hipError_t do_finalize(smc_filter_s* h, int first_emit, uint32_t t_emit) {
+    constexpr int TH = 256;
+    const size_t lds = table_lds_bytes(h->v.nseg_p2, TH, 1);
+    hipLaunchKernelGGL((k_finalize<TH>), dim3(h->v.ntheta), dim3(TH), lds, h->stream, h->v, h->cur, first_emit, t_emit);
+    return hipGetLastError();
+}
+
+// ---- lifetime ----------------------------------------------------------------------------------
+template <class T>
+static hipError_t dalloc(T** p, size_t count) {
+    return hipMalloc((void**)p, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+}
+
+extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, uint64_t seed, int device, uint32_t flags,
+                          smc_handle* out) {
+    if (!out) return fail(SMC_EINVAL, "smc_create: out is NULL");
+    *out = nullptr;
+    const int d = model_dim_rt(model_id);
+    if (d < 0) return fail(SMC_EINVAL, "smc_create: unknown model_id " + std::to_string(model_id));
+    if (n_theta <= 0 || n_x <= 0) return fail(SMC_EINVAL, "smc_create: n_theta and n_x must be positive");
+    if (n_theta > 65535) return fail(SMC_EINVAL, "smc_create: n_theta > 65535 (grid.y limit); shard theta");
+    if (seg == 0) seg = smc_auto_seg(n_x);
+    Geo g;
+    if (!geo_for_seg(seg, g)) return fail(SMC_EINVAL, "smc_create: seg must be a power of two in [256,8192]");
+    const int64_t nseg = (n_x + seg - 1) / seg;
+    if (nseg > 4096) return fail(SMC_EINVAL, "smc_create: more than 4096 segments; use a larger seg");
+    if (n_x > ((int64_t)1 << 31)) return fail(SMC_EINVAL, "smc_create: n_x > 2^31");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail(SMC_EHIP, "smc_create: no HIP device; this library has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(SMC_EINVAL, "smc_create: bad device index");
+    HIPCHK(hipSetDevice(device));
+
+    smc_filter_s* h = new smc_filter_s();
+    h->model = model_id; h->d = d; h->device = device; h->flags = flags;
+    h->threads = g.threads; h->np = g.np;
+    FilterView& v = h->v;
+    v.n = n_x; v.seg = seg; v.nseg = (int)nseg; v.npad = nseg * seg; v.ntheta = (int)n_theta; v.seed = seed;
+    int p2 = 1;
+    while (p2 < v.nseg) p2 <<= 1;
+    v.nseg_p2 = p2;
+    v.QK = 49 - ceil_log2_i64(v.nseg);
+    h->resident_ok = (v.nseg == 1) && !(flags & SMC_FLAG_NO_RESIDENT);
+
+    const size_t np = (size_t)v.ntheta * (size_t)v.npad, ns = (size_t)v.ntheta * (size_t)v.nseg, nt = (size_t)v.ntheta;
+#define TRY(expr)                                       \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) {                         \
+            std::string m = hipGetErrorString(_e);      \
+            smc_destroy(h);                             \
+            return fail(SMC_ENOMEM, "smc_create: " #expr ": " + m); \
+        }                                               \
+    } while (0)
+    TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    TRY(hipEventCreate(&h->ev0));
+    TRY(hipEventCreate(&h->ev1));
+    TRY(dalloc(&h->d_params, nt));
+    TRY(dalloc(&h->d_stream, nt));
+    TRY(dalloc(&h->d_perm, nt));
+    TRY(dalloc(&h->d_logZ_tmp, nt));
+    for (int b = 0; b < 2; ++b) {
+        TRY(dalloc(&v.x[b], np * (size_t)d));
+        TRY(dalloc(&v.C[b], np));
+        TRY(dalloc(&v.segm[b], ns));
+        TRY(dalloc(&v.segS[b], ns));
+        TRY(dalloc(&v.segS2hi[b], ns));
+        TRY(dalloc(&v.segS2lo[b], ns));
+        TRY(hipMemsetAsync(v.x[b], 0, np * (size_t)d * 8, h->stream));
+        TRY(hipMemsetAsync(v.C[b], 0, np * 8, h->stream));
+    }
+    if (flags & SMC_FLAG_ANCESTORS) TRY(dalloc(&v.anc, np));
+    TRY(dalloc(&v.logZ, nt));
+    TRY(dalloc(&v.last_logmu, nt));
+    TRY(dalloc(&v.last_ess, nt));
+    TRY(dalloc(&v.last_g, nt));
+    TRY(dalloc(&v.last_D, nt));
+    TRY(hipMemsetAsync(v.logZ, 0, nt * 8, h->stream));
+    std::vector<uint32_t> st(nt);
+    for (size_t m = 0; m < nt; ++m) st[m] = (uint32_t)m;
+    TRY(hipMemcpyAsync(h->d_stream, st.data(), nt * 4, hipMemcpyHostToDevice, h->stream));
+    TRY(hipStreamSynchronize(h->stream));
+#undef TRY
+    v.params = h->d_params;
+    v.stream = h->d_stream;
+    *out = h;
+    return SMC_OK;
+}
+
+extern "C" int smc_destroy(smc_handle h) {
+    if (!h) return SMC_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    FilterView& v = h->v;
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segm[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]);
+    }
+    (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_g); (void)hipFree(v.last_D);
+    (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
+    (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SMC_OK;
+}
+
+extern "C" int smc_set_params(smc_handle h, const double* raw) {
+    if (!h || !raw) return fail(SMC_EINVAL, "smc_set_params: NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    const int nraw = model_nraw_rt(h->model);
+    std::vector<Params> P((size_t)h->v.ntheta);
+    for (int m = 0; m < h->v.ntheta; ++m) {
+        for (int k = 0; k < NPARAM; ++k) P[m].raw[k] = k < nraw ? raw[(size_t)m * nraw + k] : 0.0;
+        derive_params(h->model, P[m].raw, P[m].der);
+    }
+    HIPCHK(hipMemcpyAsync(h->d_params, P.data(), P.size() * sizeof(Params), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_params = true;
+    return SMC_OK;
+}
+
+extern "C" int smc_set_streams(smc_handle h, const uint32_t* s) {
+    if (!h || !s) return fail(SMC_EINVAL, "smc_set_streams: NULL argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_stream, s, (size_t)h->v.ntheta * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SMC_OK;
+}
+
+extern "C" int smc_reseed(smc_handle h, uint64_t seed) {
+    if (!h) return fail(SMC_EINVAL, "smc_reseed: NULL handle");
+    h->v.seed = seed;
+    return SMC_OK;
+}
+
+static int ensure_y(smc_handle h, int64_t T) {
+    if (T > h->ycap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_y);
+        h->d_y = nullptr;
+        HIPCHK(dalloc(&h->d_y, (size_t)T));
+        h->ycap = T;
+    }
+    return SMC_OK;
+}
+static int ensure_trace(smc_handle h, int64_t T) {
+    if (T > h->trcap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess);
+        h->d_tr_logmu = h->d_tr_ess = nullptr;
+        HIPCHK(dalloc(&h->d_tr_logmu, (size_t)T * h->v.ntheta));
+        HIPCHK(dalloc(&h->d_tr_ess, (size_t)T * h->v.ntheta));
+        h->trcap = T;
+    }
+    return SMC_OK;
+}
+
+static int ensure_recs(smc_handle h, int64_t T) {
+    if (T > h->reccap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_recs);
+        h->d_recs = nullptr;
+        HIPCHK(dalloc(&h->d_recs, (size_t)T * h->v.ntheta));
+        h->reccap = T;
+    }
+    return SMC_OK;
+}
+
+static int finish_timing(smc_handle h) {
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    return SMC_OK;
+}
+
+static int emit_if_needed(smc_handle h) {
+    if (!h->emitted) {
+        HIPCHK(do_finalize(h, h->t == 1 ? 1 : 0, h->t - 1));
+        h->emitted = true;
+    }
+    return SMC_OK;
+}
+
+// bootstrap_filter(N, y, model)   particles.jl:87-105
+extern "C" int smc_init(smc_handle h, double y1, double* logmu) {
+    if (!h) return fail(SMC_EINVAL, "smc_init: NULL handle");
+    if (!h->have_params) return fail(SMC_ESTATE, "smc_init: smc_set_params has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    h->cur = 0;
+    HIPCHK(do_init(h, y1));
+    h->t = 1; h->inited = true; h->emitted = false;
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    rc = finish_timing(h);
+    if (rc) return rc;
+    if (logmu) HIPCHK(hipMemcpy(logmu, h->v.last_logmu, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
+
+// bootstrap_filter!(x, w, y, model)   particles.jl:107-129
+extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
+    if (!h) return fail(SMC_EINVAL, "smc_step: NULL handle");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_step: call smc_init (bootstrap_filter) first");
+    HIPCHK(hipSetDevice(h->device));
+    h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(do_step(h, h->t, h->emitted ? 0 : 1, y_t));
+    h->cur ^= 1; h->t += 1; h->emitted = false;
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    rc = finish_timing(h);
+    if (rc) return rc;
+    if (logmu) HIPCHK(hipMemcpy(logmu, h->v.last_logmu, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    if (ess) HIPCHK(hipMemcpy(ess, h->v.last_ess, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
+
+// log_likelihood(N, y, model)   particles.jl:132-147
+extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, double* logZ, double* logmu_trace,
+                                  double* ess_trace) {
+    if (!h || !y) return fail(SMC_EINVAL, "smc_log_likelihood: NULL argument");
+    if (T <= 0) return fail(SMC_EINVAL, "smc_log_likelihood: T must be positive");
+    if (!h->have_params) return fail(SMC_ESTATE, "smc_log_likelihood: smc_set_params has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_y(h, T);
+    if (rc) return rc;
+    const bool want_trace = logmu_trace || ess_trace;
+    if (want_trace && (rc = ensure_trace(h, T))) return rc;
+    const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
+    if (resident && (rc = ensure_recs(h, T))) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
+    h->v.y = h->d_y;
+    h->v.trace_logmu = want_trace ? h->d_tr_logmu : nullptr;
+    h->v.trace_ess = want_trace ? h->d_tr_ess : nullptr;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    h->cur = 0;
+    if (resident) {
+        HIPCHK(launch_resident(h->model, h->v, (int)T, h->d_recs, h->stream));
+        h->cur = 0; h->t = (uint32_t)T; h->inited = true; h->emitted = true;
+    } else {
+        HIPCHK(do_init(h, y[0]));
+        h->t = 1; h->inited = true; h->emitted = false;
+        for (int64_t t = 1; t < T; ++t) {
+            HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
+            h->cur ^= 1; h->t += 1;
+        }
+        rc = emit_if_needed(h);
+        if (rc) return rc;
+    }
+    rc = finish_timing(h);
+    h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
+    if (rc) return rc;
+    if (logZ) HIPCHK(hipMemcpy(logZ, h->v.logZ, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    if (logmu_trace) HIPCHK(hipMemcpy(logmu_trace, h->d_tr_logmu, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    if (ess_trace) HIPCHK(hipMemcpy(ess_trace, h->d_tr_ess, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
+
+extern "C" int smc_get_state(smc_handle h, double* x, double* w, int32_t* anc) {
+    if (!h) return fail(SMC_EINVAL, "smc_get_state: NULL handle");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_get_state: filter not initialised");
+    HIPCHK(hipSetDevice(h->device));
+    const FilterView& v = h->v;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t rows = (size_t)h->d * v.ntheta;
+    if (x)
+        HIPCHK(hipMemcpy2D(x, (size_t)v.n * 8, v.x[h->cur], (size_t)v.npad * 8, (size_t)v.n * 8, rows,
+                           hipMemcpyDeviceToHost));
+    if (anc) {
+        if (!v.anc) return fail(SMC_ESTATE, "smc_get_state: handle created without SMC_FLAG_ANCESTORS");
+        HIPCHK(hipMemcpy2D(anc, (size_t)v.n * 4, v.anc, (size_t)v.npad * 4, (size_t)v.n * 4, (size_t)v.ntheta,
+                           hipMemcpyDeviceToHost));
+    }
+    if (w) {
+        int rc = emit_if_needed(h);
+        if (rc) return rc;
+        if (!h->d_wdense) HIPCHK(dalloc(&h->d_wdense, (size_t)v.ntheta * v.n));
+        hipLaunchKernelGGL(k_dense_weights, dim3((unsigned)((v.n + 255) / 256), v.ntheta), dim3(256), 0, h->stream, v,
+                           h->cur, h->d_wdense);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(w, h->d_wdense, (size_t)v.ntheta * v.n * 8, hipMemcpyDeviceToHost));
+    }
+    return SMC_OK;
+}
+
+extern "C" int smc_get_logZ(smc_handle h, double* logZ, double* ess) {
+    if (!h) return fail(SMC_EINVAL, "smc_get_logZ: NULL handle");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_get_logZ: filter not initialised");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (logZ) HIPCHK(hipMemcpy(logZ, h->v.logZ, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    if (ess) HIPCHK(hipMemcpy(ess, h->v.last_ess, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
+
+extern "C" int smc_permute(smc_handle h, const int32_t* a) {
+    if (!h || !a) return fail(SMC_EINVAL, "smc_permute: NULL argument");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_permute: filter not initialised");
+    for (int m = 0; m < h->v.ntheta; ++m)
+        if (a[m] < 0 || a[m] >= h->v.ntheta) return fail(SMC_EINVAL, "smc_permute: index out of range");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    const FilterView& v = h->v;
+    HIPCHK(hipMemcpyAsync(h->d_perm, a, (size_t)v.ntheta * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_logZ_tmp, v.logZ, (size_t)v.ntheta * 8, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)((v.npad + 255) / 256), v.ntheta), dim3(256), 0, h->stream, v, h->cur, h->d,
+                       h->d_perm, h->d_logZ_tmp);
+    HIPCHK(hipGetLastError());
+    h->cur ^= 1;
+    // last_* (g, D, logmu, ess) describe slot-local weights: recompute them for the new layout
+    HIPCHK(hipMemcpyAsync(h->d_logZ_tmp, v.logZ, (size_t)v.ntheta * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(do_finalize(h, 0, h->t - 1));
+    HIPCHK(hipMemcpyAsync(v.logZ, h->d_logZ_tmp, (size_t)v.ntheta * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SMC_OK;
+}
+
+extern "C" int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo) {
+    if (!h) return fail(SMC_EINVAL, "smc_get_weights_raw: NULL handle");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_get_weights_raw: filter not initialised");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const FilterView& v = h->v;
+    const size_t np = (size_t)v.ntheta * v.npad * 8, ns = (size_t)v.ntheta * v.nseg * 8;
+    const int c = h->cur;
+    if (C) HIPCHK(hipMemcpy(C, v.C[c], np, hipMemcpyDeviceToHost));
+    if (m) HIPCHK(hipMemcpy(m, v.segm[c], ns, hipMemcpyDeviceToHost));
+    if (S) HIPCHK(hipMemcpy(S, v.segS[c], ns, hipMemcpyDeviceToHost));
+    if (S2hi) HIPCHK(hipMemcpy(S2hi, v.segS2hi[c], ns, hipMemcpyDeviceToHost));
+    if (S2lo) HIPCHK(hipMemcpy(S2lo, v.segS2lo[c], ns, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
+
+extern "C" int smc_get_geometry(smc_handle h, int* seg, int* nseg, int* d, int* resident) {
+    if (!h) return fail(SMC_EINVAL, "smc_get_geometry: NULL handle");
+    if (seg) *seg = h->v.seg;
+    if (nseg) *nseg = h->v.nseg;
+    if (d) *d = h->d;
+    if (resident) *resident = (h->resident_ok && resident_supported(h->model, h->v.seg)) ? 1 : 0;
+    return SMC_OK;
+}
+
+extern "C" int smc_last_elapsed_ms(smc_handle h, double* ms) {
+    if (!h || !ms) return fail(SMC_EINVAL, "smc_last_elapsed_ms: NULL argument");
+    *ms = h->last_ms;
+    return SMC_OK;
+}
+
+extern "C" int smc_synchronize(smc_handle h) {
+    if (!h) return fail(SMC_EINVAL, "smc_synchronize: NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SMC_OK;
+}
+
+// ---- stand-alone normalize / resample ------------------------------------------------------------
+static int fix_bits_for(int64_t n) {
+    const int k = 62 - ceil_log2_i64(n);
+    return k > FIX_BITS ? FIX_BITS : k;
+}
+
+extern "C" int smc_normalize(const double* logw, int64_t n, double* w, double* logmu, double* ess, int device) {
+    if (!logw || !w || n <= 0) return fail(SMC_EINVAL, "smc_normalize: bad argument");
+    HIPCHK(hipSetDevice(device));
+    double *d_in = nullptr, *d_w = nullptr, *d_o = nullptr;
+    HIPCHK(dalloc(&d_in, (size_t)n));
+    HIPCHK(dalloc(&d_w, (size_t)n));
+    HIPCHK(dalloc(&d_o, 2));
+    HIPCHK(hipMemcpy(d_in, logw, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_normalize<1024>), dim3(1), dim3(1024), 0, 0, d_in, n, fix_bits_for(n), d_w, d_o);
+    HIPCHK(hipGetLastError());
+    double o[2];
+    HIPCHK(hipMemcpy(w, d_w, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(o, d_o, 16, hipMemcpyDeviceToHost));
+    if (logmu) *logmu = o[0];
+    if (ess) *ess = o[1];
+    (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_o);
+    return SMC_OK;
+}
+
+extern "C" int smc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t seed, uint32_t stream, uint32_t t,
+                            int32_t* a, int device) {
+    if (!w || !a || n <= 0 || ndraw < 0) return fail(SMC_EINVAL, "smc_resample: bad argument");
+    if (n > ((int64_t)1 << 31)) return fail(SMC_EINVAL, "smc_resample: n > 2^31");
+    if (ndraw == 0) return SMC_OK;
+    HIPCHK(hipSetDevice(device));
+    double* d_w = nullptr;
+    uint64_t* d_C = nullptr;
+    int32_t* d_a = nullptr;
+    int* d_st = nullptr;
+    HIPCHK(dalloc(&d_w, (size_t)n));
+    HIPCHK(dalloc(&d_C, (size_t)n));
+    HIPCHK(dalloc(&d_a, (size_t)ndraw));
+    HIPCHK(dalloc(&d_st, 1));
+    HIPCHK(hipMemcpy(d_w, w, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_resample_cdf<1024>), dim3(1), dim3(1024), 0, 0, d_w, n, fix_bits_for(n), d_C, d_st);
+    HIPCHK(hipGetLastError());
+    int st = 0;
+    HIPCHK(hipMemcpy(&st, d_st, 4, hipMemcpyDeviceToHost));
+    int rc = SMC_OK;
+    if (st != 0) {
+        rc = fail(SMC_EINVAL, "smc_resample: weights must be finite with a positive maximum");
+    } else {
+        hipLaunchKernelGGL(k_resample_draw, dim3((unsigned)((ndraw + 255) / 256)), dim3(256), 0, 0, d_C, n, ndraw, seed,
+                           stream, t, d_a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(a, d_a, (size_t)ndraw * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(d_w); (void)hipFree(d_C); (void)hipFree(d_a); (void)hipFree(d_st);
+    return rc;
+}
+
+// ---- host-side helpers ---------------------------------------------------------------------------
+template <int MODEL>
+static void simulate_t(const Params& p, int64_t T, uint64_t seed, double* x, double* y) {
+    constexpr int D = model_dim<MODEL>::value;
+    double xc[D], xn[D], z[D], z1, mean, sd;
+    for (int64_t t = 0; t < T; ++t) {
+        for (int c = 0; c < D; ++c) box_muller(draw(seed, 0u, SIM_STREAM, (uint32_t)t, SLOT_NORMAL0 + c), z[c], z1);
+        if (t == 0) model_initial<MODEL>(p, z, xn); else model_transition<MODEL>(p, xc, z, xn);
+        model_obs_moments<MODEL>(p, xn, mean, sd);
+        double e;
+        box_muller(draw(seed, 0u, SIM_STREAM, (uint32_t)t, SLOT_OBS), e, z1);
+        y[t] = fma(sd, e, mean);
+        for (int c = 0; c < D; ++c) { xc[c] = xn[c]; if (x) x[(size_t)c * T + t] = xn[c]; }
+    }
+}
+
+extern "C" int smc_simulate(int model_id, const double* raw, int64_t T, uint64_t seed, double* x, double* y) {
+    const int nraw = model_nraw_rt(model_id);
+    if (nraw < 0 || !raw || !y || T <= 0) return fail(SMC_EINVAL, "smc_simulate: bad argument");
+    Params p;
+    for (int k = 0; k < NPARAM; ++k) p.raw[k] = k < nraw ? raw[k] : 0.0;
+    derive_params(model_id, p.raw, p.der);
+    switch (model_id) {
+    case MODEL_LG1D: simulate_t<MODEL_LG1D>(p, T, seed, x, y); break;
+    case MODEL_SV1D: simulate_t<MODEL_SV1D>(p, T, seed, x, y); break;
+    default: simulate_t<MODEL_UCSV3D>(p, T, seed, x, y); break;
+    }
+    return SMC_OK;
+}
+
+extern "C" double smc_host_exp(double x) { return sp_exp(x); }
+extern "C" double smc_host_log(double x) { return sp_log(x); }
+extern "C" void smc_host_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    const u32x4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+extern "C" void smc_host_box_muller(const uint32_t w[4], double* z0, double* z1) {
+    box_muller(u32x4{{w[0], w[1], w[2], w[3]}}, *z0, *z1);
+}
+
+__global__ void k_device_math(int which, const double* a, const double* b, int64_t n, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i];
+    double r = 0.0;
+    if (which == 0) r = sp_exp(x);
+    else if (which == 1) r = sp_log(x);
+    else if (which == 2) r = sqrt(x);
+    else if (which == 3 || which == 4) {
+        const uint64_t ua = d2bits(x), ub = d2bits(b[i]);
+        double z0, z1;
+        box_muller(u32x4{{(uint32_t)ua, (uint32_t)(ua >> 32), (uint32_t)ub, (uint32_t)(ub >> 32)}}, z0, z1);
+        r = which == 3 ? z0 : z1;
+    } else if (which == 5) r = x / b[i];
+    out[i] = r;
+}
+
+extern "C" int smc_device_math(int which, const double* a, const double* b, int64_t n, double* out, int device) {
+    if (!a || !out || n <= 0 || which < 0 || which > 5) return fail(SMC_EINVAL, "smc_device_math: bad argument");
+    if (which >= 3 && !b) return fail(SMC_EINVAL, "smc_device_math: b required");
+    HIPCHK(hipSetDevice(device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(dalloc(&da, (size_t)n));
+    HIPCHK(dalloc(&db, (size_t)n));
+    HIPCHK(dalloc(&dout, (size_t)n));
+    HIPCHK(hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (b) HIPCHK(hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_device_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which, da, db, n, dout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return SMC_OK;
+}

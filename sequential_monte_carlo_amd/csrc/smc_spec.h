@@ -1,0 +1,313 @@
+// smc_spec.h -- numerical specification of the particle-filter hot path, host + device.
+//
+// Everything a particle ever computes is defined here with IEEE-754 binary64 +,-,*,/,sqrt,
+// explicit fma() and integer arithmetic only, so that a gfx950 lane and a host core produce
+// the same bits (DESIGN.md "Numerical specification").  Compile with -ffp-contract=off.
+//
+// Reference semantics being implemented (charlesknipp/sequential_monte_carlo @ v1):
+//   rand(Normal(mu,sigma)), logpdf(Normal(mu,sigma),y)   src/particles.jl:97-98,123-124
+//   model methods                                        src/state_space_models.jl:87-109,233-259
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SMC_HD __host__ __device__ __forceinline__
+
+namespace smc {
+
+// ---- model ids (C ABI values) ---------------------------------------------------------
+constexpr int MODEL_LG1D = 1;    // UnivariateLinearGaussian  ssm.jl:74-109
+constexpr int MODEL_SV1D = 2;    // stochastic volatility (SURVEY A7'; obs template ssm.jl:244-247)
+constexpr int MODEL_UCSV3D = 3;  // UCSV                      ssm.jl:215-263
+constexpr int NPARAM = 8;        // padded row length of raw / derived parameter tables
+
+constexpr int FIX_BITS = 48;     // q = rint(exp(logw - m_seg) * 2^48)
+constexpr int MAX_SEG = 8192;
+constexpr uint32_t SIM_STREAM = 0xFFFFFFFFu;
+constexpr uint32_t SLOT_RESAMPLE = 0u;
+constexpr uint32_t SLOT_NORMAL0 = 1u;
+constexpr uint32_t SLOT_OBS = 8u;
+
+constexpr double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
+constexpr double INV_LN2 = 0x1.71547652b82fep+0;
+constexpr double LN2_HI = 0x1.62e42fee00000p-1;
+constexpr double LN2_LO = 0x1.a39ef35793c76p-33;
+constexpr double SQRT2 = 0x1.6a09e667f3bcdp+0;
+constexpr double PIO4 = 0x1.921fb54442d18p-1;
+constexpr double TWO_M53 = 0x1p-53;
+constexpr double TWO_M48 = 0x1p-48;
+constexpr double TWO_P48 = 0x1p+48;
+constexpr double TWO_M96 = 0x1p-96;
+constexpr double TWO_P64 = 0x1p+64;
+
+template <int MODEL> struct model_dim { static constexpr int value = (MODEL == MODEL_UCSV3D) ? 3 : 1; };
+
+SMC_HD int model_dim_rt(int id) { return id == MODEL_UCSV3D ? 3 : (id == MODEL_LG1D || id == MODEL_SV1D) ? 1 : -1; }
+SMC_HD int model_nraw_rt(int id) { return id == MODEL_LG1D ? 6 : id == MODEL_SV1D ? 3 : id == MODEL_UCSV3D ? 5 : -1; }
+
+// ---- bit casts -------------------------------------------------------------------------
+SMC_HD double bits2d(uint64_t b) { return __builtin_bit_cast(double, b); }
+SMC_HD uint64_t d2bits(double d) { return __builtin_bit_cast(uint64_t, d); }
+SMC_HD double pow2i(int k) { return bits2d((uint64_t)(k + 1023) << 52); }  // 2^k, k in [-1022,1023]
+SMC_HD double inf() { return bits2d(0x7ff0000000000000ULL); }
+
+// round to nearest even: signed |v| < 2^51 ; non-negative of any size
+SMC_HD double rne(double v) { return (v + 0x1.8p52) - 0x1.8p52; }
+SMC_HD double rne_pos(double v) { return v < 0x1p52 ? (v + 0x1p52) - 0x1p52 : v; }
+
+// ---- Philox4x32-10 ---------------------------------------------------------------------
+struct u32x4 { uint32_t v[4]; };
+
+SMC_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+SMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u32x4{{c0, c1, c2, c3}};
+}
+
+SMC_HD u32x4 draw(uint64_t seed, uint32_t pair, uint32_t stream, uint32_t t, uint32_t slot) {
+    return philox4x32_10(pair, stream, t, slot, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// ---- exp / log / sincos ----------------------------------------------------------------
+SMC_HD double sp_exp(double x) {
+    if (x != x) return x;
+    if (!(x > -708.0)) return 0.0;
+    if (x > 709.0) return inf();
+    const double k = rne(x * INV_LN2);
+    double r = fma(-k, LN2_HI, x);
+    r = fma(-k, LN2_LO, r);
+    double p = 0x1.6124613a86d09p-33;
+    p = fma(p, r, 0x1.1eed8eff8d898p-29);
+    p = fma(p, r, 0x1.ae64567f544e4p-26);
+    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
+    p = fma(p, r, 0x1.71de3a556c734p-19);
+    p = fma(p, r, 0x1.a01a01a01a01ap-16);
+    p = fma(p, r, 0x1.a01a01a01a01ap-13);
+    p = fma(p, r, 0x1.6c16c16c16c17p-10);
+    p = fma(p, r, 0x1.1111111111111p-7);
+    p = fma(p, r, 0x1.5555555555555p-5);
+    p = fma(p, r, 0x1.5555555555555p-3);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return p * pow2i((int)k);
+}
+
+SMC_HD double sp_log(double x) {
+    if (x != x || x < 0.0) return bits2d(0x7ff8000000000000ULL);
+    if (x == 0.0) return -inf();
+    if (x == inf()) return x;
+    int e = 0;
+    if (x < 0x1p-1022) { x *= 0x1p54; e = -54; }
+    const uint64_t b = d2bits(x);
+    e += (int)((b >> 52) & 0x7ff) - 1023;
+    double m = bits2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
+    if (m > SQRT2) { m *= 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double R = 0x1.642c8590b2164p-4;
+    R = fma(R, z, 0x1.8618618618618p-4);
+    R = fma(R, z, 0x1.af286bca1af28p-4);
+    R = fma(R, z, 0x1.e1e1e1e1e1e1ep-4);
+    R = fma(R, z, 0x1.1111111111111p-3);
+    R = fma(R, z, 0x1.3b13b13b13b14p-3);
+    R = fma(R, z, 0x1.745d1745d1746p-3);
+    R = fma(R, z, 0x1.c71c71c71c71cp-3);
+    R = fma(R, z, 0x1.2492492492492p-2);
+    R = fma(R, z, 0x1.999999999999ap-2);
+    R = fma(R, z, 0x1.5555555555555p-1);
+    R = R * z;
+    const double dk = (double)e;
+    return dk * LN2_HI - ((s * (f - R) - dk * LN2_LO) - f);
+}
+
+// cos, sin of 2*pi*u for u in [0,1) a multiple of 2^-53
+SMC_HD void sp_sincos2pi(double u, double& c, double& s) {
+    const double a = 8.0 * u;
+    const int oct = (int)a;
+    double g = a - (double)oct;
+    if (oct & 1) g = 1.0 - g;
+    const double y = g * PIO4;
+    const double z = y * y;
+    double ps = 0x1.952c77030ad4ap-49;
+    ps = fma(ps, z, -0x1.ae7f3e733b81fp-41);
+    ps = fma(ps, z, 0x1.6124613a86d09p-33);
+    ps = fma(ps, z, -0x1.ae64567f544e4p-26);
+    ps = fma(ps, z, 0x1.71de3a556c734p-19);
+    ps = fma(ps, z, -0x1.a01a01a01a01ap-13);
+    ps = fma(ps, z, 0x1.1111111111111p-7);
+    ps = fma(ps, z, -0x1.5555555555555p-3);
+    const double sy = fma(y * z, ps, y);
+    double pc = -0x1.6827863b97d97p-53;
+    pc = fma(pc, z, 0x1.ae7f3e733b81fp-45);
+    pc = fma(pc, z, -0x1.93974a8c07c9dp-37);
+    pc = fma(pc, z, 0x1.1eed8eff8d898p-29);
+    pc = fma(pc, z, -0x1.27e4fb7789f5cp-22);
+    pc = fma(pc, z, 0x1.a01a01a01a01ap-16);
+    pc = fma(pc, z, -0x1.6c16c16c16c17p-10);
+    pc = fma(pc, z, 0x1.5555555555555p-5);
+    pc = fma(pc, z, -0.5);
+    const double cy = fma(z, pc, 1.0);
+    const bool swap = ((oct + 1) & 2) != 0;
+    double cc = swap ? sy : cy;
+    double ss = swap ? cy : sy;
+    if ((oct + 2) & 4) cc = -cc;
+    if (oct & 4) ss = -ss;
+    c = cc;
+    s = ss;
+}
+
+// four Philox words -> (z0, z1) iid N(0,1); z0 belongs to particle 2p, z1 to 2p+1
+SMC_HD void box_muller(const u32x4& w, double& z0, double& z1) {
+    const uint64_t n1 = (((uint64_t)w.v[1] << 32) | w.v[0]) >> 11;
+    const uint64_t n2 = (((uint64_t)w.v[3] << 32) | w.v[2]) >> 11;
+    const double u1 = (double)(n1 + 1) * TWO_M53;
+    const double u2 = (double)n2 * TWO_M53;
+    const double r = sqrt(-2.0 * sp_log(u1));
+    double c, s;
+    sp_sincos2pi(u2, c, s);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+// ---- 64x64 -> 128 multiply ---------------------------------------------------------------
+SMC_HD void mul64wide(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    hi = __umul64hi(a, b);
+    lo = a * b;
+#else
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    hi = (uint64_t)(p >> 64);
+    lo = (uint64_t)p;
+#endif
+}
+
+SMC_HD double u128_to_double(uint64_t hi, uint64_t lo) { return (double)hi * TWO_P64 + (double)lo; }
+
+SMC_HD int ceil_log2_i64(int64_t n) {
+    int k = 0;
+    while (((int64_t)1 << k) < n) ++k;
+    return k;
+}
+
+SMC_HD uint64_t to_fix48(double wrel) { return (uint64_t)rne_pos(wrel * TWO_P48); }
+
+// ---- models ------------------------------------------------------------------------------
+// raw rows:  LG1D (A,B,Q,R,x0,sigma0)  Q,R,sigma0 VARIANCES (ssm.jl:93,102,108)
+//            SV1D (mu,rho,sigma)
+//            UCSV (gamma_eps,gamma_eta,x0,lse0,lsn0)  gammas STD-DEVs (ssm.jl:239-240)
+// der rows:  LG1D (sQ,sR,s0,1/sR,c_obs)   SV1D (s0)
+struct Params {
+    double raw[NPARAM];
+    double der[NPARAM];
+};
+
+SMC_HD void derive_params(int model, const double* raw, double* der) {
+    for (int k = 0; k < NPARAM; ++k) der[k] = 0.0;
+    if (model == MODEL_LG1D) {
+        const double sR = sqrt(raw[3]);
+        der[0] = sqrt(raw[2]);
+        der[1] = sR;
+        der[2] = sqrt(raw[5]);
+        der[3] = 1.0 / sR;
+        der[4] = -HALF_LOG2PI - sp_log(sR);
+    } else if (model == MODEL_SV1D) {
+        der[0] = raw[2] / sqrt(1.0 - raw[1] * raw[1]);
+    }
+}
+
+// x = rand(initial_dist(model))            ssm.jl:105-109, 249-259
+template <int MODEL>
+SMC_HD void model_initial(const Params& p, const double* z, double* x) {
+    if constexpr (MODEL == MODEL_LG1D) {
+        x[0] = fma(p.der[2], z[0], p.raw[4]);
+    } else if constexpr (MODEL == MODEL_SV1D) {
+        x[0] = fma(p.der[0], z[0], p.raw[0]);
+    } else {
+        x[0] = fma(sp_exp(0.5 * p.raw[3]), z[0], p.raw[2]);
+        x[1] = fma(p.raw[0], z[1], p.raw[3]);
+        x[2] = fma(p.raw[1], z[2], p.raw[4]);
+    }
+}
+
+// x = rand(transition(model, xp))          ssm.jl:87-94, 233-242
+template <int MODEL>
+SMC_HD void model_transition(const Params& p, const double* xp, const double* z, double* x) {
+    if constexpr (MODEL == MODEL_LG1D) {
+        x[0] = fma(p.der[0], z[0], p.raw[0] * xp[0]);
+    } else if constexpr (MODEL == MODEL_SV1D) {
+        x[0] = fma(p.raw[2], z[0], fma(p.raw[1], xp[0] - p.raw[0], p.raw[0]));
+    } else {
+        x[0] = fma(sp_exp(0.5 * xp[1]), z[0], xp[0]);
+        x[1] = fma(p.raw[0], z[1], xp[1]);
+        x[2] = fma(p.raw[1], z[2], xp[2]);
+    }
+}
+
+// logpdf(observation(model, x), y)          ssm.jl:96-103, 244-247
+template <int MODEL>
+SMC_HD double model_logobs(const Params& p, const double* x, double y) {
+    double z, c;
+    if constexpr (MODEL == MODEL_LG1D) {
+        z = (y - p.raw[1] * x[0]) * p.der[3];
+        c = p.der[4];
+    } else if constexpr (MODEL == MODEL_SV1D) {
+        z = y * sp_exp(-0.5 * x[0]);
+        c = fma(-0.5, x[0], -HALF_LOG2PI);
+    } else {
+        z = (y - x[0]) * sp_exp(-0.5 * x[2]);
+        c = fma(-0.5, x[2], -HALF_LOG2PI);
+    }
+    return fma(-0.5 * z, z, c);
+}
+
+template <int MODEL>
+SMC_HD void model_obs_moments(const Params& p, const double* x, double& mean, double& sd) {
+    if constexpr (MODEL == MODEL_LG1D) {
+        mean = p.raw[1] * x[0];
+        sd = p.der[1];
+    } else if constexpr (MODEL == MODEL_SV1D) {
+        mean = 0.0;
+        sd = sp_exp(0.5 * x[0]);
+    } else {
+        mean = x[0];
+        sd = sp_exp(0.5 * x[2]);
+    }
+}
+
+// ---- segment combine: one entry of the segment table --------------------------------------
+// Q_b = rint(sumw_b * exp(m_b - g) * 2^QK),  R_b = rint(sumw2_b * exp(m_b - g)^2 * 2^QK)
+SMC_HD void seg_entry(double m_b, uint64_t S, uint64_t S2hi, uint64_t S2lo, double g, int QK, uint64_t& Qb,
+                      uint64_t& Rb) {
+    const double e = (g > -inf()) ? sp_exp(m_b - g) : 0.0;
+    const double qscale = pow2i(QK);
+    const double sw = (double)S * TWO_M48;
+    const double sw2 = u128_to_double(S2hi, S2lo) * TWO_M96;
+    Qb = (uint64_t)rne_pos(sw * e * qscale);
+    Rb = (uint64_t)rne_pos(sw2 * e * e * qscale);
+}
+
+SMC_HD void combine_outputs(double g, uint64_t Dtot, uint64_t Rtot, int QK, int64_t n, double& logmu, double& ess) {
+    const double inv = pow2i(-QK);
+    const double Dd = (double)Dtot * inv, Rd = (double)Rtot * inv;
+    logmu = Dtot ? (g + sp_log(Dd)) - sp_log((double)n) : -inf();
+    ess = Rtot ? Dd * Dd / Rd : 0.0;
+}
+
+}  // namespace smc
