@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/sec of the bootstrap-filter hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
+
+One "step" = one pass of the hot path over one batch of synthetic input = one
+log_likelihood(N, y, model) call (src/particles.jl:132-147) for every filter on the rank.
+
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+  c2  univariate linear-Gaussian, Nx = 2^20, T = 1000, ONE filter per GPU.
+At N > 1 the filter (theta) axis is what shards: every rank runs its own filter with
+its own Philox stream (global theta index = rank) and no data-path collective; the only exchange
+is the outer reweight of src/smc_samplers.jl:232 -- one RCCL all-gather of the N logZ scalars per
+pass, followed by the replicated normalize.  Weak scaling (per-GPU work fixed).
+Other workloads (for DESIGN.md; same code path): c3 SV Nx=2^20 T=5000; c4 LG 512x1024 T=200;
+c5 UCSV 512-per-GPU x 1024 T=200 (theta sharded, N_theta = 512*N).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+LG = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0]
+SV = [-1.0, 0.95, 0.25]
+UC = [0.2, 0.2, 3.0, 0.0, 0.0]
+
+WORKLOADS = {
+    # name: (model, raw, n_theta per GPU, Nx, T, description)
+    "c2": (1, LG, 1, 1 << 20, 1000, "LinearGaussian1D bootstrap filter Nx=2^20 T=1000 (BASELINE configs[1])"),
+    "c3": (2, SV, 1, 1 << 20, 5000, "StochasticVolatility1D bootstrap filter Nx=2^20 T=5000 (BASELINE configs[2])"),
+    "c4": (1, LG, 512, 1024, 200, "LinearGaussian1D batched inner filters Ntheta=512 x Nx=1024 T=200 (configs[3] shape)"),
+    "c5": (3, UC, 512, 1024, 200, "UCSV batched inner filters Ntheta=512/GPU x Nx=1024 T=200 (configs[4] shape)"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--seg", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    from sequential_monte_carlo_amd import _lib as L
+
+    model, raw, nth, nx, T, desc = WORKLOADS[args.workload]
+    _, y = L.simulate(model, raw if model != 3 else UC, T, 1998)
+    if args.workload == "c5":
+        rng = np.random.default_rng(1234 + rank)
+        raws = np.tile(raw, (nth, 1))
+        raws[:, 0] = raws[:, 1] = rng.uniform(0.05, 0.6, nth)
+    else:
+        raws = np.tile(raw, (nth, 1))
+    h = L.Handle(model, nth, nx, seg=args.seg, seed=1, device=local_rank if world > 1 else 0)
+    h.set_params(raws)
+    h.set_streams(np.arange(nth, dtype=np.uint32) + rank * nth)      # global theta index
+
+    def sync_all():
+        h.synchronize()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def one_pass():
+        logZ = h.log_likelihood(y)          # inputs (y) are 8 KB; state lives in HBM
+        if dist is not None:
+            # outer reweight (smc_samplers.jl:232): all-gather the logZ scalars over xGMI, then the
+            # replicated normalize on every rank (identical results everywhere)
+            mine = torch.from_numpy(logZ).cuda()
+            allz = torch.empty(world * nth, dtype=torch.float64, device="cuda")
+            dist.all_gather_into_tensor(allz, mine)
+            z = allz.cpu().numpy()
+            zmax = z.max()
+            wts = np.exp(z - zmax)
+            _ = zmax + np.log(wts.sum()) - np.log(z.size)
+        return logZ
+
+    for _ in range(args.warmup):
+        one_pass()
+    sync_all()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(args.steps):
+        logZ = one_pass()
+        dev_ms += h.elapsed_ms()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    psteps = float(nth) * nx * T * args.steps * world
+    value = psteps / elapsed
+
+    # ---- roofline of the dominant kernel -----------------------------------------------------
+    d = {1: 1, 2: 1, 3: 3}[model]
+    bytes_per_pstep = 32 + 16 * d                      # 48 B (d=1), 80 B (d=3)
+    roof = None
+    if rank == 0:
+        if h.resident:
+            # one k_resident launch does the whole series: HIP-event time of the call
+            ms = dev_ms / args.steps
+            units = float(nth) * nx * T
+            kname = "k_resident"
+        else:
+            avg_ms, min_ms = h.time_step_kernel(y[: min(T, 400)], nsample=64)
+            ms = avg_ms
+            units = float(nth) * nx
+            kname = "k_step"
+        achieved = units * bytes_per_pstep / (ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "launch_ms": round(ms, 6), "algorithmic_bytes_per_launch": units * bytes_per_pstep}
+
+    # ---- CPU baseline: the oracle (scalar port of particles.jl), bounded sample -----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        ob.build()
+        if nth == 1:
+            Ts = 24
+            f = ob.Filter(model, raw, nx, seg=h.seg, seed=1, stream=0)
+            c0 = time.perf_counter()
+            f.log_likelihood(y[:Ts])
+            cdt = time.perf_counter() - c0
+            cval = nx * Ts / cdt
+            sample = "same filter (Nx=%d), first %d of T=%d observations, 1 thread" % (nx, Ts, T)
+        else:
+            ns = 24
+            c0 = time.perf_counter()
+            ob.log_likelihood_batch(model, raws[:ns], nx, y, seg=h.seg, seed=1, stream0=0)
+            cdt = time.perf_counter() - c0
+            cval = ns * nx * T / cdt
+            sample = "first %d of %d filters (Nx=%d, T=%d), 1 thread" % (ns, nth, nx, T)
+        cpu = {"value": round(cval, 1), "unit": "particle-steps/s", "cores": 1, "kind": "port", "sample": sample,
+               "seconds": round(cdt, 2)}
+
+    if rank == 0:
+        out = {
+            "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "n_theta_per_gpu": nth, "n_x": nx, "T": T, "seg": h.seg,
+                       "resident_kernel": bool(h.resident), "sharding": "theta axis, %d filter(s) per GPU" % nth,
+                       "logZ_rank0_theta0": float(logZ[0])},
+            "device_ms_per_step": dev_ms / args.steps,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

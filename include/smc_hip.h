@@ -81,6 +81,10 @@ int smc_get_geometry(smc_handle h, int* seg, int* nseg, int* d, int* resident);
 /* device time (HIP events on the handle's stream) of the last init/step/log_likelihood call */
 int smc_last_elapsed_ms(smc_handle h, double* ms);
 int smc_synchronize(smc_handle h);
+/* roofline measurement: runs log_likelihood through the one-launch-per-step path and brackets
+ * `nsample` evenly spaced k_step launches with HIP events on the handle's stream; returns the
+ * average / minimum bracketed duration of ONE k_step launch in milliseconds. */
+int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, int nsample, double* avg_ms, double* min_ms);
 
 /* ---- stand-alone A1 / A2 ---------------------------------------------------------------------*/
 /* normalize(logw) -> (logmu, w, ess)                        src/particles.jl:5-15

@@ -384,6 +384,47 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     return SMC_OK;
 }
 
+extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, int nsample, double* avg_ms,
+                                    double* min_ms) {
+    if (!h || !y || T < 2 || nsample < 1) return fail(SMC_EINVAL, "smc_time_step_kernel: bad argument");
+    if (!h->have_params) return fail(SMC_ESTATE, "smc_time_step_kernel: smc_set_params has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_y(h, T);
+    if (rc) return rc;
+    if (nsample > T - 1) nsample = (int)(T - 1);
+    std::vector<hipEvent_t> e0((size_t)nsample), e1((size_t)nsample);
+    for (int i = 0; i < nsample; ++i) { HIPCHK(hipEventCreate(&e0[i])); HIPCHK(hipEventCreate(&e1[i])); }
+    HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
+    h->v.y = h->d_y; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
+    h->cur = 0;
+    HIPCHK(do_init(h, y[0]));
+    h->t = 1; h->inited = true; h->emitted = false;
+    const int64_t stride = (T - 1) / nsample;
+    int k = 0;
+    for (int64_t t = 1; t < T; ++t) {
+        const bool s = k < nsample && ((t - 1) % stride) == stride / 2;
+        if (s) HIPCHK(hipEventRecord(e0[k], h->stream));
+        HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
+        if (s) { HIPCHK(hipEventRecord(e1[k], h->stream)); ++k; }
+        h->cur ^= 1; h->t += 1;
+    }
+    rc = emit_if_needed(h);
+    h->v.y = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double sum = 0.0, mn = 1e30;
+    for (int i = 0; i < k; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0[i], e1[i]));
+        sum += ms;
+        mn = ms < mn ? ms : mn;
+    }
+    for (int i = 0; i < nsample; ++i) { (void)hipEventDestroy(e0[i]); (void)hipEventDestroy(e1[i]); }
+    if (avg_ms) *avg_ms = k ? sum / k : 0.0;
+    if (min_ms) *min_ms = k ? mn : 0.0;
+    return SMC_OK;
+}
+
 extern "C" int smc_get_state(smc_handle h, double* x, double* w, int32_t* anc) {
     if (!h) return fail(SMC_EINVAL, "smc_get_state: NULL handle");
     if (!h->inited) return fail(SMC_ESTATE, "smc_get_state: filter not initialised");

