@@ -29,12 +29,14 @@
  *   - normals: Box-Muller on two 53-bit uniforms; one Philox call serves the particle
  *     pair (2p, 2p+1): z[2p] = R cos(2 pi u2), z[2p+1] = R sin(2 pi u2).
  *   - exp / log / sincos: the polynomial kernels below (IEEE +,-,*,/,sqrt and fma only).
- *   - weights are carried as 2^48 fixed point (q = rint(exp(logw - m) * 2^48)) so that
- *     every sum and every prefix sum is an exact integer: the result does not depend on
- *     the order in which a parallel machine adds them up.
- *   - a filter with more than `seg` particles normalises each segment of `seg` particles
- *     against its own maximum and combines the segments through a second, integer,
- *     table (two-level multinomial draw).  iid multinomial law as in StatsBase.sample.
+ *   - exp(logw_i) is split as p_i * 2^k_i (k_i integer, p_i in [0.707,1.415]); a segment of
+ *     `seg` particles is normalised against the power of two 2^kb, kb = max k_i (instead of
+ *     the reference's maximum(logw), particles.jl:6 -- same role, exact to undo), and weights
+ *     are carried as fixed point q_i = rint(p_i * 2^(48 + k_i - kb)), so every sum and prefix
+ *     sum is an exact integer and independent of the order a parallel machine adds in.
+ *   - segments are combined by integer shifts (2^(K - kb), K = max kb) into a second table:
+ *     two-level multinomial draw from one 64-bit number.  iid multinomial law as in
+ *     StatsBase.sample(1:n, Weights(w), N).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; never -ffast-math).
  */
@@ -67,9 +69,6 @@ static const double SQRT2 = 0x1.6a09e667f3bcdp+0;
 static const double PIO4 = 0x1.921fb54442d18p-1;
 static const double RND_MAGIC = 0x1.8p52;
 static const double TWO_M53 = 0x1p-53;
-static const double TWO_M48 = 0x1p-48;
-static const double TWO_P48 = 0x1p+48;
-static const double TWO_M96 = 0x1p-96;
 static const double TWO_P64 = 0x1p+64;
 
 /* ------------------------------------------------------------------------------------ */
@@ -109,10 +108,9 @@ static uint64_t d2bits(double d) { uint64_t b; memcpy(&b, &d, 8); return b; }
 static double rne(double v) { return (v + RND_MAGIC) - RND_MAGIC; }
 static double rne_pos(double v) { return v < 0x1p52 ? (v + 0x1p52) - 0x1p52 : v; }
 
-double orc_exp(double x) {
-    if (x != x) return x;
-    if (!(x > -708.0)) return 0.0;
-    if (x > 709.0) return INFINITY;
+/* exp(x) = p * 2^k with k = rint(x/ln2) (returned as an integral double), p in [0.707,1.415];
+ * |x| <= 1e15 */
+static double exp_parts(double x, double* kout) {
     double k = rne(x * INV_LN2);
     double r = fma(-k, LN2_HI, x);
     r = fma(-k, LN2_LO, r);
@@ -130,8 +128,26 @@ double orc_exp(double x) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    int64_t ki = (int64_t)k;
-    return p * bits2d((uint64_t)(ki + 1023) << 52);
+    *kout = k;
+    return p;
+}
+
+double orc_exp(double x) {
+    if (x != x) return x;
+    if (!(x > -708.0)) return 0.0;
+    if (x > 709.0) return INFINITY;
+    double k;
+    double p = exp_parts(x, &k);
+    return p * bits2d((uint64_t)((int64_t)k + 1023) << 52);
+}
+
+/* a log-weight takes part in the normalisation iff it is a number of sane magnitude */
+static int lw_alive(double l) { return l == l && fabs(l) <= 1e15; }
+
+/* q = rint(p * 2^(bits + dk)), dk = k_i - kb <= 0 (integral doubles) */
+static uint64_t fix_weight(double p, double dk, int bits) {
+    if (dk < -(double)(bits + 2)) return 0;
+    return (uint64_t)rne_pos(p * bits2d((uint64_t)(bits + (int)dk + 1023) << 52));
 }
 
 double orc_log(double x) {
@@ -354,30 +370,33 @@ int orc_simulate(int id, const double* raw, int T, uint64_t seed, double* x, dou
 /* A1/A2 stand-alone: normalize(logw) and resample(w, N)    particles.jl:5-19            */
 /* (single level; used for the outer theta-level `reweight`/`resample`)                  */
 /* ------------------------------------------------------------------------------------ */
-static int fix_bits_for(int64_t n) { int k = 62 - ceil_log2(n); return k > FIX_BITS ? FIX_BITS : k; }
+static int fix_bits_for(int64_t n) { int k = 61 - ceil_log2(n); return k > FIX_BITS ? FIX_BITS : k; }
 
 static uint64_t to_fix(double wrel, double scale) { return (uint64_t)rne_pos(wrel * scale); }
 
 int orc_normalize(const double* logw, int64_t n, double* w, double* logmu, double* ess) {
     if (n <= 0) return -1;
-    double maxw = -INFINITY;                                     /* maxw = maximum(logw)     */
-    for (int64_t i = 0; i < n; ++i) if (logw[i] > maxw) maxw = logw[i];
-    int K = fix_bits_for(n);
-    double scale = bits2d((uint64_t)(K + 1023) << 52);
-    uint64_t S = 0; u128 S2 = 0;
+    const int K = fix_bits_for(n);
+    double* p = (double*)malloc(sizeof(double) * (size_t)n);
+    double* k = (double*)malloc(sizeof(double) * (size_t)n);
     uint64_t* q = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
+    double kmax = -INFINITY;                                     /* maxw = maximum(logw)     */
+    for (int64_t i = 0; i < n; ++i) {
+        if (lw_alive(logw[i])) { p[i] = exp_parts(logw[i], &k[i]); if (k[i] > kmax) kmax = k[i]; }
+        else { p[i] = 0.0; k[i] = -INFINITY; }
+    }
+    uint64_t S = 0; u128 S2 = 0;
     for (int64_t i = 0; i < n; ++i) {                            /* w = exp.(logw .- maxw)   */
-        double e = (logw[i] == logw[i] && maxw > -INFINITY) ? orc_exp(logw[i] - maxw) : 0.0;
-        q[i] = to_fix(e, scale);
+        q[i] = (k[i] > -INFINITY) ? fix_weight(p[i], k[i] - kmax, K) : 0;
         S += q[i];                                               /* sumw = sum(w)            */
         S2 += (u128)q[i] * q[i];
     }
     double Sd = (double)S;
-    *logmu = S ? (maxw + orc_log(Sd * bits2d((uint64_t)(1023 - K) << 52))) - orc_log((double)n)
+    *logmu = S ? fma(kmax, LN2_HI, fma(kmax, LN2_LO, orc_log(Sd * bits2d((uint64_t)(1023 - K) << 52)))) - orc_log((double)n)
                : -INFINITY;                                      /* maxw+log(sumw)-log(N)    */
     for (int64_t i = 0; i < n; ++i) w[i] = S ? (double)q[i] / Sd : 0.0;   /* w = w/sumw      */
     *ess = S ? (Sd * Sd) / u128_to_double((uint64_t)(S2 >> 64), (uint64_t)S2) : 0.0;   /* 1/sum(w.^2) */
-    free(q);
+    free(p); free(k); free(q);
     return 0;
 }
 
@@ -413,102 +432,102 @@ int orc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t seed, uint3
 typedef struct {
     int64_t n;      /* particles                                   */
     int seg, nseg;  /* segment length (power of two), #segments    */
-    int QK;         /* fixed-point bits of the segment table       */
+    int SH;         /* extra right shift of the segment table: max(0, ceil_log2(nseg*seg) - 14) */
     uint64_t* C;    /* [nseg*seg] segment-local inclusive sums of q */
-    double* m;      /* [nseg] segment max of logw                   */
+    double* kb;     /* [nseg] segment exponent (integral; -inf if no live particle) */
     uint64_t *S, *S2hi, *S2lo;   /* [nseg] sum q, sum q^2 (128 bit) */
     /* global combine */
-    double gmax;
-    uint64_t* Dcum; /* [nseg] inclusive sums of Q_b                 */
-    double* fd;     /* [nseg] S_b / Q_b                             */
+    double K;       /* max kb */
+    uint64_t* Dcum; /* [nseg] inclusive sums of Q_b = S_b >> sh_b  */
+    int* sh;        /* [nseg] sh_b = (K - kb) + SH, or 64 if the segment is out of range */
     uint64_t Dtot, Rtot;
     double logmu, ess;
 } orc_weights;
 
 static void weights_alloc(orc_weights* W, int64_t n, int seg) {
     W->n = n; W->seg = seg; W->nseg = (int)((n + seg - 1) / seg);
-    int shn = ceil_log2(W->nseg);
-    W->QK = 49 - shn;
+    int sh = ceil_log2((int64_t)W->nseg * seg) - 14;
+    W->SH = sh > 0 ? sh : 0;
     size_t ns = (size_t)W->nseg;
     W->C = (uint64_t*)calloc(ns * (size_t)seg, 8);
-    W->m = (double*)calloc(ns, 8);
+    W->kb = (double*)calloc(ns, 8);
     W->S = (uint64_t*)calloc(ns, 8);
     W->S2hi = (uint64_t*)calloc(ns, 8);
     W->S2lo = (uint64_t*)calloc(ns, 8);
     W->Dcum = (uint64_t*)calloc(ns, 8);
-    W->fd = (double*)calloc(ns, 8);
+    W->sh = (int*)calloc(ns, sizeof(int));
 }
 static void weights_free(orc_weights* W) {
-    free(W->C); free(W->m); free(W->S); free(W->S2hi); free(W->S2lo); free(W->Dcum); free(W->fd);
+    free(W->C); free(W->kb); free(W->S); free(W->S2hi); free(W->S2lo); free(W->Dcum); free(W->sh);
 }
 
 /* normalize(logw) of particles.jl:5-15, segment by segment, then the integer combine */
 static void weights_normalize(orc_weights* W, const double* logw) {
     const int seg = W->seg;
+    double p[MAX_SEG], k[MAX_SEG];
     for (int b = 0; b < W->nseg; ++b) {
         int64_t i0 = (int64_t)b * seg, i1 = i0 + seg < W->n ? i0 + seg : W->n;
-        double mb = -INFINITY;
-        for (int64_t i = i0; i < i1; ++i) if (logw[i] > mb) mb = logw[i];   /* NaN never wins */
+        double kb = -INFINITY;
+        for (int64_t i = i0; i < i1; ++i) {
+            if (lw_alive(logw[i])) { p[i - i0] = exp_parts(logw[i], &k[i - i0]); if (k[i - i0] > kb) kb = k[i - i0]; }
+            else k[i - i0] = -INFINITY;
+        }
         uint64_t acc = 0; u128 acc2 = 0;
         for (int64_t i = i0; i < i0 + seg; ++i) {
             uint64_t q = 0;
-            if (i < i1 && logw[i] == logw[i] && mb > -INFINITY) q = to_fix(orc_exp(logw[i] - mb), TWO_P48);
+            if (i < i1 && k[i - i0] > -INFINITY) q = fix_weight(p[i - i0], k[i - i0] - kb, FIX_BITS);
             acc += q; acc2 += (u128)q * q;
             W->C[i] = acc;
         }
-        W->m[b] = mb; W->S[b] = acc; W->S2hi[b] = (uint64_t)(acc2 >> 64); W->S2lo[b] = (uint64_t)acc2;
+        W->kb[b] = kb; W->S[b] = acc; W->S2hi[b] = (uint64_t)(acc2 >> 64); W->S2lo[b] = (uint64_t)acc2;
     }
     /* combine: what the next step's kernel prologue (or the finalize kernel) computes */
-    double g = -INFINITY;
-    for (int b = 0; b < W->nseg; ++b) if (W->m[b] > g) g = W->m[b];
-    W->gmax = g;
-    double qscale = bits2d((uint64_t)(W->QK + 1023) << 52);
+    double K = -INFINITY;
+    for (int b = 0; b < W->nseg; ++b) if (W->kb[b] > K) K = W->kb[b];
+    W->K = K;
     uint64_t D = 0, R = 0;
     for (int b = 0; b < W->nseg; ++b) {
-        double e = (g > -INFINITY) ? orc_exp(W->m[b] - g) : 0.0;
-        double sw = (double)W->S[b] * TWO_M48;
-        double sw2 = u128_to_double(W->S2hi[b], W->S2lo[b]) * TWO_M96;
-        uint64_t Qb = (uint64_t)rne_pos(sw * e * qscale);
-        uint64_t Rb = (uint64_t)rne_pos(sw2 * e * e * qscale);
+        double dk = K - W->kb[b];                        /* >= 0, integral, inf or nan if dead */
+        int sh = (dk >= 0.0 && dk < 64.0) ? (int)dk + W->SH : 64;
+        if (sh > 64) sh = 64;
+        uint64_t Qb = sh < 64 ? W->S[b] >> sh : 0;
+        int sh2 = 2 * (sh - W->SH) + 49 + W->SH;          /* shift of the 128-bit sum of squares */
+        u128 s2 = ((u128)W->S2hi[b] << 64) | W->S2lo[b];
+        uint64_t Rb = (sh < 64 && sh2 < 128) ? (uint64_t)(s2 >> sh2) : 0;
         D += Qb; R += Rb;
         W->Dcum[b] = D;
-        W->fd[b] = Qb ? (double)W->S[b] / (double)Qb : 0.0;
+        W->sh[b] = sh;
     }
     W->Dtot = D; W->Rtot = R;
-    double inv = bits2d((uint64_t)(1023 - W->QK) << 52);
-    double Dd = (double)D * inv, Rd = (double)R * inv;
-    W->logmu = D ? (g + orc_log(Dd)) - orc_log((double)W->n) : -INFINITY;
+    double Dd = (double)D * bits2d((uint64_t)(1023 + W->SH - 48) << 52);
+    double Rd = (double)R * bits2d((uint64_t)(1023 + W->SH - 47) << 52);
+    W->logmu = D ? fma(K, LN2_HI, fma(K, LN2_LO, orc_log(Dd))) - orc_log((double)W->n) : -INFINITY;
     W->ess = R ? Dd * Dd / Rd : 0.0;
 }
 
-/* ancestor of particle i: one 64-bit draw, two-level inverse CDF */
+/* ancestor of particle i: one 64-bit draw, two-level inverse CDF, integers only */
 static int64_t weights_draw(const orc_weights* W, uint64_t r, int64_t i) {
     if (W->Dtot == 0) return i;                                  /* collapsed filter: identity */
-    if (W->nseg == 1) {
-        uint64_t T2 = (uint64_t)(((u128)r * W->S[0]) >> 64);
-        return upper_bound_u64(W->C, W->seg, T2);
-    }
     u128 P = (u128)r * W->Dtot;
     uint64_t T1 = (uint64_t)(P >> 64), lo = (uint64_t)P;
     int64_t b = upper_bound_u64(W->Dcum, W->nseg, T1);
-    uint64_t rho = T1 - (b ? W->Dcum[b - 1] : 0);
-    double pos = ((double)rho + (double)(lo >> 11) * TWO_M53) * W->fd[b];
-    uint64_t T2 = (uint64_t)pos;
-    if (T2 > W->S[b] - 1) T2 = W->S[b] - 1;
+    uint64_t rho = T1 - (b ? W->Dcum[b - 1] : 0);                /* uniform on [0, Q_b)        */
+    int s = W->sh[b];
+    uint64_t T2 = s ? (rho << s) | (lo >> (64 - s)) : rho;       /* uniform on [0, Q_b << s)   */
     return b * W->seg + upper_bound_u64(W->C + (size_t)b * W->seg, W->seg, T2);
 }
 
 /* dense normalised weights w_i (what the reference's normalize returns as `w`) */
 static void weights_dense(const orc_weights* W, double* w) {
-    double inv = bits2d((uint64_t)(1023 - W->QK) << 52);
-    double Dd = (double)W->Dtot * inv;
+    double Dd = (double)W->Dtot * bits2d((uint64_t)(1023 + W->SH - 48) << 52);
     for (int b = 0; b < W->nseg; ++b) {
-        double e = (W->gmax > -INFINITY) ? orc_exp(W->m[b] - W->gmax) : 0.0;
+        double dk = W->K - W->kb[b];
+        double sc = (dk >= 0.0 && dk < 900.0) ? bits2d((uint64_t)(1023 - 48 - (int)dk) << 52) : 0.0;
         for (int j = 0; j < W->seg; ++j) {
             int64_t i = (int64_t)b * W->seg + j;
             if (i >= W->n) break;
             uint64_t q = W->C[i] - (j ? W->C[i - 1] : 0);
-            w[i] = W->Dtot ? ((double)q * TWO_M48) * e / Dd : 0.0;
+            w[i] = W->Dtot ? ((double)q * sc) / Dd : 0.0;
         }
     }
 }
@@ -629,12 +648,12 @@ void orc_filter_get_state(const orc_filter* f, double* x, double* w, int64_t* a,
 double orc_filter_ess(const orc_filter* f) { return f->W.ess; }
 int orc_filter_seg(const orc_filter* f) { return f->W.seg; }
 
-/* raw internal weights state, for kernel-level parity tests: C [nseg*seg], m/S/S2hi/S2lo [nseg] */
+/* raw internal weights state, for kernel-level parity tests: C [nseg*seg], kb/S/S2hi/S2lo [nseg] */
 void orc_filter_get_weights_raw(const orc_filter* f, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi,
                                 uint64_t* S2lo) {
     size_t ns = (size_t)f->W.nseg;
     if (C) memcpy(C, f->W.C, 8 * ns * (size_t)f->W.seg);
-    if (m) memcpy(m, f->W.m, 8 * ns);
+    if (m) memcpy(m, f->W.kb, 8 * ns);
     if (S) memcpy(S, f->W.S, 8 * ns);
     if (S2hi) memcpy(S2hi, f->W.S2hi, 8 * ns);
     if (S2lo) memcpy(S2lo, f->W.S2lo, 8 * ns);

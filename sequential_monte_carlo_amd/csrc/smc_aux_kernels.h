@@ -1,0 +1,142 @@
+// smc_aux_kernels.h -- kernels off the hot path (state read-back, outer resample!, stand-alone
+// normalize / resample).  Included by smc_capi.hip only.
+#pragma once
+#include "smc_kernels.h"
+
+namespace smc {
+
+// ---------------------------------------------------------------------------------------------
+// dense normalised weights w_i (normalize()'s `w`, particles.jl:11) for smc_get_state
+// ---------------------------------------------------------------------------------------------
+__global__ void k_dense_weights(FilterView v, int cur, double* w /*[ntheta][n]*/) {
+    const int th = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.n) return;
+    const double K = v.last_K[th];
+    const uint64_t Dtot = v.last_D[th];
+    const int b = (int)(i / v.seg), j = (int)(i % v.seg);
+    const uint64_t* C = v.C[cur] + (size_t)th * v.npad;
+    const uint64_t q = C[i] - (j ? C[i - 1] : 0);
+    const double dk = K - v.segk[cur][(size_t)th * v.nseg + b];
+    const double sc = (dk >= 0.0 && dk < 900.0) ? pow2i(-48 - (int)dk) : 0.0;
+    const double Dd = (double)Dtot * pow2i(v.SH - 48);
+    w[(size_t)th * v.n + i] = Dtot ? ((double)q * sc) / Dd : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// outer resample!(smc) (smc_samplers.jl:74-84): theta slot m <- slot a[m], value copy of the
+// whole filter state (x cloud, C, segment records, logZ).  grid (blocks, ntheta)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_permute(FilterView v, int cur, int d, const int32_t* a, const double* logZ_src) {
+    const int th = blockIdx.y, src = a[th], nxt = cur ^ 1;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < v.npad) {
+        for (int c = 0; c < d; ++c)
+            v.x[nxt][((size_t)c * v.ntheta + th) * v.npad + i] = v.x[cur][((size_t)c * v.ntheta + src) * v.npad + i];
+        v.C[nxt][(size_t)th * v.npad + i] = v.C[cur][(size_t)src * v.npad + i];
+    }
+    if (i < v.nseg) {
+        const size_t o = (size_t)th * v.nseg + i, s = (size_t)src * v.nseg + i;
+        v.segk[nxt][o] = v.segk[cur][s];
+        v.segS[nxt][o] = v.segS[cur][s];
+        v.segS2hi[nxt][o] = v.segS2hi[cur][s];
+        v.segS2lo[nxt][o] = v.segS2lo[cur][s];
+    }
+    if (i == 0) v.logZ[th] = logZ_src[src];
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone A1 / A2 (outer theta-level reweight / resample; n <= a few thousand): one
+// workgroup, single level, all integer sums.
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_normalize(const double* logw, int64_t n, int K, double* w, double* out2) {
+    constexpr int NW = THREADS / WAVE;
+    __shared__ double red[NW];
+    __shared__ uint64_t acc[3][NW];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    double kmax = -inf();
+    for (int64_t i = tid; i < n; i += THREADS) {
+        const double l = logw[i];
+        if (lw_alive(l)) { double k; (void)sp_exp_parts(l, k); kmax = k > kmax ? k : kmax; }
+    }
+    kmax = block_max<THREADS>(kmax, red);
+    uint64_t S = 0;
+    U128 s2{0, 0};
+    for (int64_t i = tid; i < n; i += THREADS) {
+        const double l = logw[i];
+        uint64_t q = 0;
+        if (lw_alive(l)) { double k; const double p = sp_exp_parts(l, k); q = fix_weight(p, k - kmax, K); }
+        S += q;
+        s2 = add128(s2, sq128(q));
+    }
+    S = wave_sum(S);
+    s2 = wave_sum128(s2);
+    if (lane == 0) { acc[0][wave] = S; acc[1][wave] = s2.lo; acc[2][wave] = s2.hi; }
+    __syncthreads();
+    uint64_t St = 0;
+    U128 t2{0, 0};
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { St += acc[0][k]; t2 = add128(t2, U128{acc[1][k], acc[2][k]}); }
+    const double Sd = (double)St;
+    for (int64_t i = tid; i < n; i += THREADS) {
+        const double l = logw[i];
+        uint64_t q = 0;
+        if (lw_alive(l)) { double k; const double p = sp_exp_parts(l, k); q = fix_weight(p, k - kmax, K); }
+        w[i] = St ? (double)q / Sd : 0.0;
+    }
+    if (tid == 0) {
+        out2[0] = St ? fma(kmax, LN2_HI, fma(kmax, LN2_LO, sp_log(Sd * pow2i(-K)))) - sp_log((double)n) : -inf();
+        out2[1] = St ? (Sd * Sd) / u128_to_double(t2.hi, t2.lo) : 0.0;
+    }
+}
+
+// q_i = rint(w_i / wmax * 2^K) ; C = inclusive scan (single workgroup, chunked)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_resample_cdf(const double* w, int64_t n, int K, uint64_t* C, int* status) {
+    constexpr int NW = THREADS / WAVE;
+    __shared__ double red[NW];
+    __shared__ uint64_t wt[NW];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    double m = 0.0;
+    for (int64_t i = tid; i < n; i += THREADS) { const double x = w[i]; m = x > m ? x : m; }
+    m = block_max<THREADS>(m, red);
+    if (!(m > 0.0) || m == inf()) { if (tid == 0) *status = -2; return; }
+    const double scale = pow2i(K);
+    uint64_t carry = 0;
+    for (int64_t base = 0; base < n; base += THREADS) {
+        const int64_t i = base + tid;
+        uint64_t q = 0;
+        if (i < n) { const double r = w[i] / m; q = (r == r && r > 0.0) ? (uint64_t)rne_pos(r * scale) : 0; }
+        const uint64_t incl = wave_incl_scan(q, lane);
+        if (lane == WAVE - 1) wt[wave] = incl;
+        __syncthreads();
+        uint64_t off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { off += (k < wave) ? wt[k] : 0; tot += wt[k]; }
+        if (i < n) C[i] = carry + off + incl;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *status = 0;
+}
+
+__global__ void k_resample_draw(const uint64_t* C, int64_t n, int64_t ndraw, uint64_t seed, uint32_t stream, uint32_t t,
+                                int32_t* a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ndraw) return;
+    const u32x4 rw = draw(seed, (uint32_t)(i >> 1), stream, t, SLOT_RESAMPLE);
+    const int j = (int)(i & 1);
+    const uint64_t r = ((uint64_t)rw.v[2 * j + 1] << 32) | rw.v[2 * j];
+    const uint64_t S = C[n - 1];
+    uint64_t T, lo;
+    mul64wide(r, S, T, lo);
+    int64_t l = 0, h = n;
+    while (l < h) {
+        const int64_t mid = (l + h) >> 1;
+        if (C[mid] > T) h = mid; else l = mid + 1;
+    }
+    a[i] = (int32_t)(l < n ? l : n - 1);
+}
+
+}  // namespace smc

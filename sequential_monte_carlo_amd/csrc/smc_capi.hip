@@ -2,11 +2,12 @@
 // Handle-owned device state, one HIP stream per handle, HIP-event timing of every call.
 // There is NO CPU fallback: every filter entry point launches HIP kernels or fails.
 #include "../../include/smc_hip.h"
-#include "smc_kernels.h"
-#include "smc_resident.h"
+#include "smc_launch.h"
+#include "smc_aux_kernels.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,13 +50,21 @@ struct smc_filter_s {
     bool emitted = false;  // logmu/ess of the current weights already produced
     bool have_params = false;
     bool resident_ok = false;
-    int threads = 0, np = 0;
+    Geo geo{0, 0};
     double last_ms = 0.0;
 };
 
 // ---- geometry ------------------------------------------------------------------------------
-struct Geo { int threads, np; };
-static bool geo_for_seg(int seg, Geo& g) {
+namespace smc {
+bool geo_valid(int seg, int np, Geo& g) {
+    if (np != 1 && np != 2 && np != 4) return false;
+    const int th = seg / (2 * np);
+    if (th * 2 * np != seg) return false;
+    if (!(th == 128 || th == 256 || th == 512 || th == 1024 || (th == 64 && np == 2))) return false;
+    g = {th, np};
+    return true;
+}
+bool geo_default(int seg, Geo& g) {
     switch (seg) {
     case 256: g = {128, 1}; return true;
     case 512: g = {256, 1}; return true;
@@ -66,6 +75,7 @@ static bool geo_for_seg(int seg, Geo& g) {
     }
     return false;
 }
+}  // namespace smc
 
 extern "C" int smc_auto_seg(int64_t n) {
     if (n > MAX_SEG) return 2048;
@@ -84,42 +94,30 @@ extern "C" int smc_device_count(void) {
 }
 
 // ---- kernel dispatch -------------------------------------------------------------------------
-template <int MODEL, int THREADS, int NP>
-static hipError_t launch_init(smc_filter_s* h, double y) {
-    const size_t lds = scr_words(THREADS, NP) * 8;
-    hipLaunchKernelGGL((k_init<MODEL, THREADS, NP>), dim3(h->v.nseg, h->v.ntheta), dim3(THREADS), lds, h->stream, h->v,
-                       h->cur, y);
-    return hipGetLastError();
-}
-template <int MODEL, int THREADS, int NP>
-static hipError_t launch_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) {
-    const size_t lds = table_lds_bytes(h->v.nseg_p2, THREADS, NP);
-    hipLaunchKernelGGL((k_step<MODEL, THREADS, NP>), dim3(h->v.nseg, h->v.ntheta), dim3(THREADS), lds, h->stream, h->v,
-                       h->cur, t, emit_prev, y);
-    return hipGetLastError();
-}
-
-#define DISPATCH_GEO(MODEL, FN, ...)                                           \
-    switch (h->v.seg) {                                                        \
-    case 256: return FN<MODEL, 128, 1>(__VA_ARGS__);                           \
-    case 512: return FN<MODEL, 256, 1>(__VA_ARGS__);                           \
-    case 1024: return FN<MODEL, 256, 2>(__VA_ARGS__);                          \
-    case 2048: return FN<MODEL, 256, 4>(__VA_ARGS__);                          \
-    case 4096: return FN<MODEL, 512, 4>(__VA_ARGS__);                          \
-    case 8192: return FN<MODEL, 1024, 4>(__VA_ARGS__);                         \
-    }                                                                          \
+static hipError_t do_init(smc_filter_s* h, double y) {
+    switch (h->model) {
+    case MODEL_LG1D: return launch_init<MODEL_LG1D>(h->v, h->geo, h->cur, y, h->stream);
+    case MODEL_SV1D: return launch_init<MODEL_SV1D>(h->v, h->geo, h->cur, y, h->stream);
+    case MODEL_UCSV3D: return launch_init<MODEL_UCSV3D>(h->v, h->geo, h->cur, y, h->stream);
+    }
     return hipErrorInvalidValue;
-
-#define DISPATCH(FN, ...)                                                      \
-    switch (h->model) {                                                        \
-    case MODEL_LG1D: DISPATCH_GEO(MODEL_LG1D, FN, __VA_ARGS__)                 \
-    case MODEL_SV1D: DISPATCH_GEO(MODEL_SV1D, FN, __VA_ARGS__)                 \
-    case MODEL_UCSV3D: DISPATCH_GEO(MODEL_UCSV3D, FN, __VA_ARGS__)             \
-    }                                                                          \
+}
+static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) {
+    switch (h->model) {
+    case MODEL_LG1D: return launch_step<MODEL_LG1D>(h->v, h->geo, h->cur, t, emit_prev, y, h->stream);
+    case MODEL_SV1D: return launch_step<MODEL_SV1D>(h->v, h->geo, h->cur, t, emit_prev, y, h->stream);
+    case MODEL_UCSV3D: return launch_step<MODEL_UCSV3D>(h->v, h->geo, h->cur, t, emit_prev, y, h->stream);
+    }
     return hipErrorInvalidValue;
-
-static hipError_t do_init(smc_filter_s* h, double y) { DISPATCH(launch_init, h, y) }
-static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) { DISPATCH(launch_step, h, t, emit_prev, y) }
+}
+static hipError_t do_resident(smc_filter_s* h, int T) {
+    switch (h->model) {
+    case MODEL_LG1D: return launch_resident<MODEL_LG1D>(h->v, T, h->d_recs, h->stream);
+    case MODEL_SV1D: return launch_resident<MODEL_SV1D>(h->v, T, h->d_recs, h->stream);
+    case MODEL_UCSV3D: return launch_resident<MODEL_UCSV3D>(h->v, T, h->d_recs, h->stream);
+    }
+    return hipErrorInvalidValue;
+}
 
 static hipError_t do_finalize(smc_filter_s* h, int first_emit, uint32_t t_emit) {
     constexpr int TH = 256;
@@ -144,7 +142,11 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     if (n_theta > 65535) return fail(SMC_EINVAL, "smc_create: n_theta > 65535 (grid.y limit); shard theta");
     if (seg == 0) seg = smc_auto_seg(n_x);
     Geo g;
-    if (!geo_for_seg(seg, g)) return fail(SMC_EINVAL, "smc_create: seg must be a power of two in [256,8192]");
+    if (!geo_default(seg, g)) return fail(SMC_EINVAL, "smc_create: seg must be a power of two in [256,8192]");
+    if (const char* e = getenv("SMC_NP")) {   // tuning knob: particle pairs per thread (1, 2 or 4)
+        Geo g2;
+        if (geo_valid(seg, atoi(e), g2)) g = g2;
+    }
     const int64_t nseg = (n_x + seg - 1) / seg;
     if (nseg > 4096) return fail(SMC_EINVAL, "smc_create: more than 4096 segments; use a larger seg");
     if (n_x > ((int64_t)1 << 31)) return fail(SMC_EINVAL, "smc_create: n_x > 2^31");
@@ -156,13 +158,13 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
 
     smc_filter_s* h = new smc_filter_s();
     h->model = model_id; h->d = d; h->device = device; h->flags = flags;
-    h->threads = g.threads; h->np = g.np;
+    h->geo = g;
     FilterView& v = h->v;
     v.n = n_x; v.seg = seg; v.nseg = (int)nseg; v.npad = nseg * seg; v.ntheta = (int)n_theta; v.seed = seed;
     int p2 = 1;
     while (p2 < v.nseg) p2 <<= 1;
     v.nseg_p2 = p2;
-    v.QK = 49 - ceil_log2_i64(v.nseg);
+    v.SH = table_shift_extra(v.npad);
     h->resident_ok = (v.nseg == 1) && !(flags & SMC_FLAG_NO_RESIDENT);
 
     const size_t np = (size_t)v.ntheta * (size_t)v.npad, ns = (size_t)v.ntheta * (size_t)v.nseg, nt = (size_t)v.ntheta;
@@ -185,7 +187,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     for (int b = 0; b < 2; ++b) {
         TRY(dalloc(&v.x[b], np * (size_t)d));
         TRY(dalloc(&v.C[b], np));
-        TRY(dalloc(&v.segm[b], ns));
+        TRY(dalloc(&v.segk[b], ns));
         TRY(dalloc(&v.segS[b], ns));
         TRY(dalloc(&v.segS2hi[b], ns));
         TRY(dalloc(&v.segS2lo[b], ns));
@@ -196,7 +198,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     TRY(dalloc(&v.logZ, nt));
     TRY(dalloc(&v.last_logmu, nt));
     TRY(dalloc(&v.last_ess, nt));
-    TRY(dalloc(&v.last_g, nt));
+    TRY(dalloc(&v.last_K, nt));
     TRY(dalloc(&v.last_D, nt));
     TRY(hipMemsetAsync(v.logZ, 0, nt * 8, h->stream));
     std::vector<uint32_t> st(nt);
@@ -216,9 +218,9 @@ extern "C" int smc_destroy(smc_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     FilterView& v = h->v;
     for (int b = 0; b < 2; ++b) {
-        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segm[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]);
+        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]);
     }
-    (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_g); (void)hipFree(v.last_D);
+    (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -363,7 +365,7 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     h->cur = 0;
     if (resident) {
-        HIPCHK(launch_resident(h->model, h->v, (int)T, h->d_recs, h->stream));
+        HIPCHK(do_resident(h, (int)T));
         h->cur = 0; h->t = (uint32_t)T; h->inited = true; h->emitted = true;
     } else {
         HIPCHK(do_init(h, y[0]));
@@ -497,7 +499,7 @@ extern "C" int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_
     const size_t np = (size_t)v.ntheta * v.npad * 8, ns = (size_t)v.ntheta * v.nseg * 8;
     const int c = h->cur;
     if (C) HIPCHK(hipMemcpy(C, v.C[c], np, hipMemcpyDeviceToHost));
-    if (m) HIPCHK(hipMemcpy(m, v.segm[c], ns, hipMemcpyDeviceToHost));
+    if (m) HIPCHK(hipMemcpy(m, v.segk[c], ns, hipMemcpyDeviceToHost));
     if (S) HIPCHK(hipMemcpy(S, v.segS[c], ns, hipMemcpyDeviceToHost));
     if (S2hi) HIPCHK(hipMemcpy(S2hi, v.segS2hi[c], ns, hipMemcpyDeviceToHost));
     if (S2lo) HIPCHK(hipMemcpy(S2lo, v.segS2lo[c], ns, hipMemcpyDeviceToHost));
@@ -528,7 +530,7 @@ extern "C" int smc_synchronize(smc_handle h) {
 
 // ---- stand-alone normalize / resample ------------------------------------------------------------
 static int fix_bits_for(int64_t n) {
-    const int k = 62 - ceil_log2_i64(n);
+    const int k = 61 - ceil_log2_i64(n);
     return k > FIX_BITS ? FIX_BITS : k;
 }
 

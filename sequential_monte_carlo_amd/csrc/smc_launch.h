@@ -1,0 +1,21 @@
+// smc_launch.h -- launch entry points, one explicit specialisation set per model family
+// (smc_model.hip is compiled once per model with -DSMC_MODEL=<id>, in parallel).
+#pragma once
+#include "smc_kernels.h"
+#include "smc_resident.h"
+
+namespace smc {
+
+// geometry of a workgroup: SEG = 2 * np * threads
+struct Geo {
+    int threads, np;
+};
+// the default geometry of a segment size, and whether (threads, np) is an instantiated one
+bool geo_default(int seg, Geo& g);
+bool geo_valid(int seg, int np, Geo& g);
+
+template <int MODEL> hipError_t launch_init(const FilterView& v, Geo g, int nxt, double y, hipStream_t s);
+template <int MODEL> hipError_t launch_step(const FilterView& v, Geo g, int cur, uint32_t t, int emit_prev, double y, hipStream_t s);
+template <int MODEL> hipError_t launch_resident(const FilterView& v, int T, StepRec* recs, hipStream_t s);
+
+}  // namespace smc

@@ -1,0 +1,83 @@
+// smc_model.hip -- instantiates the kernels of ONE model family (-DSMC_MODEL=1|2|3) for every
+// workgroup geometry.  Three objects are built in parallel and linked into libsmchip.so.
+#include "smc_launch.h"
+
+#ifndef SMC_MODEL
+#error "compile with -DSMC_MODEL=<model id>"
+#endif
+
+namespace smc {
+
+template <int THREADS, int NP>
+static hipError_t init_t(const FilterView& v, int nxt, double y, hipStream_t s) {
+    const size_t lds = scr_words(THREADS, NP) * 8;
+    hipLaunchKernelGGL((k_init<SMC_MODEL, THREADS, NP>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, nxt, y);
+    return hipGetLastError();
+}
+template <int THREADS, int NP>
+static hipError_t step_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
+    const size_t lds = table_lds_bytes(v.nseg_p2, THREADS, NP);
+    if (v.nseg > 1)
+        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, true>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
+                           emit_prev, y);
+    else
+        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, false>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
+                           emit_prev, y);
+    return hipGetLastError();
+}
+
+#define SMC_GEO_SWITCH(FN, ...)                                                   \
+    switch (g.threads * 8 + g.np) {                                               \
+    case 64 * 8 + 2: return FN<64, 2>(__VA_ARGS__);                               \
+    case 128 * 8 + 1: return FN<128, 1>(__VA_ARGS__);                             \
+    case 128 * 8 + 2: return FN<128, 2>(__VA_ARGS__);                             \
+    case 128 * 8 + 4: return FN<128, 4>(__VA_ARGS__);                             \
+    case 256 * 8 + 1: return FN<256, 1>(__VA_ARGS__);                             \
+    case 256 * 8 + 2: return FN<256, 2>(__VA_ARGS__);                             \
+    case 256 * 8 + 4: return FN<256, 4>(__VA_ARGS__);                             \
+    case 512 * 8 + 1: return FN<512, 1>(__VA_ARGS__);                             \
+    case 512 * 8 + 2: return FN<512, 2>(__VA_ARGS__);                             \
+    case 512 * 8 + 4: return FN<512, 4>(__VA_ARGS__);                             \
+    case 1024 * 8 + 1: return FN<1024, 1>(__VA_ARGS__);                           \
+    case 1024 * 8 + 2: return FN<1024, 2>(__VA_ARGS__);                           \
+    case 1024 * 8 + 4: return FN<1024, 4>(__VA_ARGS__);                           \
+    }                                                                             \
+    return hipErrorInvalidValue;
+
+template <>
+hipError_t launch_init<SMC_MODEL>(const FilterView& v, Geo g, int nxt, double y, hipStream_t s) {
+    SMC_GEO_SWITCH(init_t, v, nxt, y, s)
+}
+template <>
+hipError_t launch_step<SMC_MODEL>(const FilterView& v, Geo g, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
+    SMC_GEO_SWITCH(step_t, v, cur, t, emit_prev, y, s)
+}
+
+template <int THREADS, int NP>
+static hipError_t resident_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
+    const size_t lds = resident_lds_bytes<SMC_MODEL>(2 * NP * THREADS, THREADS, NP);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_resident<SMC_MODEL, THREADS, NP>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_resident<SMC_MODEL, THREADS, NP>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs);
+    return hipGetLastError();
+}
+
+template <>
+hipError_t launch_resident<SMC_MODEL>(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
+    switch (v.seg) {
+    case 256: return resident_t<128, 1>(v, T, recs, s);
+    case 512: return resident_t<256, 1>(v, T, recs, s);
+    case 1024: return resident_t<256, 2>(v, T, recs, s);
+    case 2048: return resident_t<512, 2>(v, T, recs, s);
+    case 4096: return resident_t<1024, 2>(v, T, recs, s);
+    case 8192:
+        if constexpr (model_dim<SMC_MODEL>::value == 1) return resident_t<1024, 4>(v, T, recs, s);
+        else return hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace smc

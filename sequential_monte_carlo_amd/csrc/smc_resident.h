@@ -8,7 +8,7 @@
 namespace smc {
 
 // per-step record written by the loop, turned into (logmu_t, ess_t) after it
-struct StepRec { double m; uint64_t S, hi, lo; };
+struct StepRec { double kb; uint64_t S, hi, lo; };
 
 template <int MODEL>
 __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int np) {
@@ -28,36 +28,49 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     const uint32_t stream = v.stream[th];
     StepRec* rec = recs + (size_t)th * T;
 
+    constexpr int NQ = 2 * NP;
     double xn[NP][2][D];
     double lw[NP][2];
-    int anc[NP][2];
+    int anc[NQ];
     uint64_t S = 0;
 
     for (int t = 0; t < T; ++t) {
         const double y = v.y[t];
+        double xp[NQ][D];
+        if (t > 0) {
+            // a = resample(weights); xp = x[a]: the NQ searches of a thread advance level by level
+            uint64_t T2[NQ];
+            int pos[NQ];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const u32x4 rw = draw(v.seed, (uint32_t)(tid + k * THREADS), stream, (uint32_t)t, SLOT_RESAMPLE);
+                uint64_t lo;
+                mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], S, T2[2 * k], lo);
+                mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], S, T2[2 * k + 1], lo);
+                pos[2 * k] = pos[2 * k + 1] = 0;
+            }
+#pragma unroll
+            for (int s = SEG >> 1; s >= 1; s >>= 1) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) pos[i] += (Cs[pos[i] + s - 1] <= T2[i]) ? s : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int own = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+                int a = S ? pos[i] : own;
+                a = a < v.n ? a : (int)v.n - 1;
+                anc[i] = a;
+#pragma unroll
+                for (int c = 0; c < D; ++c) xp[i][c] = xs[c * SEG + a];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) anc[i] = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+        }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int i0 = 2 * (tid + k * THREADS);
             const uint32_t pg = (uint32_t)(i0 >> 1);
-            double xp[2][D];
-            if (t > 0) {
-                // a = resample(weights); xp = x[a]
-                const u32x4 rw = draw(v.seed, pg, stream, (uint32_t)t, SLOT_RESAMPLE);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const uint64_t r = ((uint64_t)rw.v[2 * j + 1] << 32) | rw.v[2 * j];
-                    uint64_t T2, lo;
-                    mul64wide(r, S, T2, lo);
-                    int a = S ? upper_bound_pow2(Cs, SEG, T2) : (i0 + j);
-                    if (a >= v.n) a = (int)v.n - 1;
-                    anc[k][j] = a;
-#pragma unroll
-                    for (int c = 0; c < D; ++c) xp[j][c] = xs[c * SEG + a];
-                }
-            } else {
-                anc[k][0] = i0;
-                anc[k][1] = i0 + 1;
-            }
             double z[D][2];
 #pragma unroll
             for (int c = 0; c < D; ++c) box_muller(draw(v.seed, pg, stream, (uint32_t)t, SLOT_NORMAL0 + c), z[c][0], z[c][1]);
@@ -66,9 +79,9 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
                 double zz[D];
 #pragma unroll
                 for (int c = 0; c < D; ++c) zz[c] = z[c][j];
-                if (t > 0) model_transition<MODEL>(prm, xp[j], zz, xn[k][j]);
+                if (t > 0) model_transition<MODEL>(prm, xp[2 * k + j], zz, xn[k][j]);
                 else model_initial<MODEL>(prm, zz, xn[k][j]);
-                lw[k][j] = (i0 + j) < v.n ? model_logobs<MODEL>(prm, xn[k][j], y) : -inf();
+                lw[k][j] = (i0 + j) < v.n ? model_logobs<MODEL>(prm, xn[k][j], y) : nan_mask();
             }
         }
         __syncthreads();  // every gather from xs / Cs is done
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         S = r.S;
         if (tid == 0) {
             StepRec o;
-            o.m = r.m; o.S = r.S; o.hi = r.hi; o.lo = r.lo;
+            o.kb = r.kb; o.S = r.S; o.hi = r.hi; o.lo = r.lo;
             rec[t] = o;
         }
         __syncthreads();  // Cs, xs complete; scr free
@@ -104,8 +117,8 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         *reinterpret_cast<ulonglong2*>(v.C[0] + (size_t)th * v.npad + i0) = *reinterpret_cast<const ulonglong2*>(Cs + i0);
         if (v.anc) {
             int2 o;
-            o.x = anc[k][0];
-            o.y = anc[k][1];
+            o.x = anc[2 * k];
+            o.y = anc[2 * k + 1];
             *reinterpret_cast<int2*>(v.anc + (size_t)th * v.npad + i0) = o;
         }
     }
@@ -115,20 +128,20 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     __syncthreads();
     for (int t = tid; t < T; t += THREADS) {
         const StepRec o = rec[t];
-        uint64_t Qb, Rb;
-        seg_entry(o.m, o.S, o.hi, o.lo, o.m, v.QK, Qb, Rb);
+        // single segment: K = kb, sh = SH = 0, so the table is (S) itself
+        const uint64_t Qb = o.S, Rb = seg_R(o.hi, o.lo, 0, 0);
         double logmu, ess;
-        combine_outputs(o.m, Qb, Rb, v.QK, v.n, logmu, ess);
+        combine_outputs(o.kb, Qb, Rb, 0, v.n, logmu, ess);
         if (v.trace_logmu) v.trace_logmu[(size_t)t * v.ntheta + th] = logmu;
         if (v.trace_ess) v.trace_ess[(size_t)t * v.ntheta + th] = ess;
         if (stage_lds) lm[t] = logmu;
-        else rec[t].m = logmu;
+        else rec[t].kb = logmu;
         if (t == T - 1) {
             v.last_logmu[th] = logmu;
             v.last_ess[th] = ess;
-            v.last_g[th] = o.m;
+            v.last_K[th] = o.kb;
             v.last_D[th] = Qb;
-            v.segm[0][th] = o.m;
+            v.segk[0][th] = o.kb;
             v.segS[0][th] = o.S;
             v.segS2hi[0][th] = o.hi;
             v.segS2lo[0][th] = o.lo;
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     if (tid == 0) {
         double z = 0.0;
         for (int t = 0; t < T; ++t) {
-            const double l = stage_lds ? lm[t] : rec[t].m;
+            const double l = stage_lds ? lm[t] : rec[t].kb;
             z = t == 0 ? l : z + l;
         }
         v.logZ[th] = z;
@@ -149,42 +162,6 @@ inline bool resident_supported(int model, int seg) {
     const int d = model_dim_rt(model);
     if (d < 0) return false;
     return (size_t)seg * 8 * (d + 1) + 2048 <= 160 * 1024;
-}
-
-template <int MODEL, int THREADS, int NP>
-static hipError_t launch_resident_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
-    const size_t lds = resident_lds_bytes<MODEL>(2 * NP * THREADS, THREADS, NP);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_resident<MODEL, THREADS, NP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((k_resident<MODEL, THREADS, NP>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs);
-    return hipGetLastError();
-}
-
-template <int MODEL>
-static hipError_t launch_resident_m(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
-    switch (v.seg) {
-    case 256: return launch_resident_t<MODEL, 128, 1>(v, T, recs, s);
-    case 512: return launch_resident_t<MODEL, 256, 1>(v, T, recs, s);
-    case 1024: return launch_resident_t<MODEL, 256, 2>(v, T, recs, s);
-    case 2048: return launch_resident_t<MODEL, 512, 2>(v, T, recs, s);
-    case 4096: return launch_resident_t<MODEL, 1024, 2>(v, T, recs, s);
-    case 8192:
-        if constexpr (model_dim<MODEL>::value == 1) return launch_resident_t<MODEL, 1024, 4>(v, T, recs, s);
-        else return hipErrorInvalidValue;
-    }
-    return hipErrorInvalidValue;
-}
-
-static hipError_t launch_resident(int model, const FilterView& v, int T, StepRec* recs, hipStream_t s) {
-    switch (model) {
-    case MODEL_LG1D: return launch_resident_m<MODEL_LG1D>(v, T, recs, s);
-    case MODEL_SV1D: return launch_resident_m<MODEL_SV1D>(v, T, recs, s);
-    case MODEL_UCSV3D: return launch_resident_m<MODEL_UCSV3D>(v, T, recs, s);
-    }
-    return hipErrorInvalidValue;
 }
 
 }  // namespace smc

@@ -21,7 +21,7 @@ constexpr int MODEL_SV1D = 2;    // stochastic volatility (SURVEY A7'; obs templ
 constexpr int MODEL_UCSV3D = 3;  // UCSV                      ssm.jl:215-263
 constexpr int NPARAM = 8;        // padded row length of raw / derived parameter tables
 
-constexpr int FIX_BITS = 48;     // q = rint(exp(logw - m_seg) * 2^48)
+constexpr int FIX_BITS = 48;     // q = rint(p * 2^(48 + k - kb)),  exp(logw) = p * 2^k
 constexpr int MAX_SEG = 8192;
 constexpr uint32_t SIM_STREAM = 0xFFFFFFFFu;
 constexpr uint32_t SLOT_RESAMPLE = 0u;
@@ -84,10 +84,8 @@ SMC_HD u32x4 draw(uint64_t seed, uint32_t pair, uint32_t stream, uint32_t t, uin
 }
 
 // ---- exp / log / sincos ----------------------------------------------------------------
-SMC_HD double sp_exp(double x) {
-    if (x != x) return x;
-    if (!(x > -708.0)) return 0.0;
-    if (x > 709.0) return inf();
+// exp(x) = p * 2^k, k = rint(x / ln2) returned as an integral double, p in [0.707, 1.415]; |x| <= 1e15
+SMC_HD double sp_exp_parts(double x, double& kout) {
     const double k = rne(x * INV_LN2);
     double r = fma(-k, LN2_HI, x);
     r = fma(-k, LN2_LO, r);
@@ -105,7 +103,26 @@ SMC_HD double sp_exp(double x) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
+    kout = k;
+    return p;
+}
+
+SMC_HD double sp_exp(double x) {
+    if (x != x) return x;
+    if (!(x > -708.0)) return 0.0;
+    if (x > 709.0) return inf();
+    double k;
+    const double p = sp_exp_parts(x, k);
     return p * pow2i((int)k);
+}
+
+// a log-weight takes part in the normalisation iff it is a number of sane magnitude
+SMC_HD bool lw_alive(double l) { return l == l && (l < 0.0 ? -l : l) <= 1e15; }
+
+// q = rint(p * 2^(bits + dk)),  dk = k_i - kb <= 0 (integral doubles)
+SMC_HD uint64_t fix_weight(double p, double dk, int bits) {
+    if (dk < -(double)(bits + 2)) return 0;
+    return (uint64_t)rne_pos(p * pow2i(bits + (int)dk));
 }
 
 SMC_HD double sp_log(double x) {
@@ -206,8 +223,6 @@ SMC_HD int ceil_log2_i64(int64_t n) {
     return k;
 }
 
-SMC_HD uint64_t to_fix48(double wrel) { return (uint64_t)rne_pos(wrel * TWO_P48); }
-
 // ---- models ------------------------------------------------------------------------------
 // raw rows:  LG1D (A,B,Q,R,x0,sigma0)  Q,R,sigma0 VARIANCES (ssm.jl:93,102,108)
 //            SV1D (mu,rho,sigma)
@@ -291,22 +306,32 @@ SMC_HD void model_obs_moments(const Params& p, const double* x, double& mean, do
     }
 }
 
-// ---- segment combine: one entry of the segment table --------------------------------------
-// Q_b = rint(sumw_b * exp(m_b - g) * 2^QK),  R_b = rint(sumw2_b * exp(m_b - g)^2 * 2^QK)
-SMC_HD void seg_entry(double m_b, uint64_t S, uint64_t S2hi, uint64_t S2lo, double g, int QK, uint64_t& Qb,
-                      uint64_t& Rb) {
-    const double e = (g > -inf()) ? sp_exp(m_b - g) : 0.0;
-    const double qscale = pow2i(QK);
-    const double sw = (double)S * TWO_M48;
-    const double sw2 = u128_to_double(S2hi, S2lo) * TWO_M96;
-    Qb = (uint64_t)rne_pos(sw * e * qscale);
-    Rb = (uint64_t)rne_pos(sw2 * e * e * qscale);
+// ---- segment combine (integers only) ----------------------------------------------------------
+// A segment record is (kb, S, S2): kb = max k_i of the segment (integral double, -inf if the segment
+// has no live particle), S = sum q, S2 = sum q^2 (128 bit).  With K = max kb:
+//   sh_b = (K - kb) + SH            right shift that brings segment b to the common scale 2^K
+//   Q_b  = S_b  >> sh_b             entry of the segment table (uint64, total < 2^63)
+//   R_b  = S2_b >> (2 (K-kb) + 49 + SH)
+SMC_HD int table_shift_extra(int64_t npad) {
+    const int s = ceil_log2_i64(npad) - 14;
+    return s > 0 ? s : 0;
 }
-
-SMC_HD void combine_outputs(double g, uint64_t Dtot, uint64_t Rtot, int QK, int64_t n, double& logmu, double& ess) {
-    const double inv = pow2i(-QK);
-    const double Dd = (double)Dtot * inv, Rd = (double)Rtot * inv;
-    logmu = Dtot ? (g + sp_log(Dd)) - sp_log((double)n) : -inf();
+SMC_HD int seg_shift(double K, double kb, int SH) {
+    const double dk = K - kb;   // >= 0 integral; inf or nan for a dead segment / dead filter
+    int sh = (dk >= 0.0 && dk < 64.0) ? (int)dk + SH : 64;
+    return sh > 64 ? 64 : sh;
+}
+SMC_HD uint64_t shr128(uint64_t hi, uint64_t lo, int s) {   // low 64 bits of (hi:lo) >> s, 0 < s < 128
+    return s >= 64 ? (hi >> (s - 64)) : ((lo >> s) | (hi << (64 - s)));
+}
+SMC_HD uint64_t seg_Q(uint64_t S, int sh) { return sh < 64 ? S >> sh : 0; }
+SMC_HD uint64_t seg_R(uint64_t S2hi, uint64_t S2lo, int sh, int SH) {
+    const int sh2 = 2 * (sh - SH) + 49 + SH;
+    return (sh < 64 && sh2 < 128) ? shr128(S2hi, S2lo, sh2) : 0;
+}
+SMC_HD void combine_outputs(double K, uint64_t Dtot, uint64_t Rtot, int SH, int64_t n, double& logmu, double& ess) {
+    const double Dd = (double)Dtot * pow2i(SH - 48), Rd = (double)Rtot * pow2i(SH - 47);
+    logmu = Dtot ? fma(K, LN2_HI, fma(K, LN2_LO, sp_log(Dd))) - sp_log((double)n) : -inf();
     ess = Rtot ? Dd * Dd / Rd : 0.0;
 }
 
