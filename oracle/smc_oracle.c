@@ -34,9 +34,13 @@
  *     the reference's maximum(logw), particles.jl:6 -- same role, exact to undo), and weights
  *     are carried as fixed point q_i = rint(p_i * 2^(48 + k_i - kb)), so every sum and prefix
  *     sum is an exact integer and independent of the order a parallel machine adds in.
- *   - segments are combined by integer shifts (2^(K - kb), K = max kb) into a second table:
- *     two-level multinomial draw from one 64-bit number.  iid multinomial law as in
- *     StatsBase.sample(1:n, Weights(w), N).
+ *   - segments are combined by integer shifts (2^(K - kb), K = max kb) into a second table.
+ *     resample (particles.jl:17-19) is the multinomial law of StatsBase.sample(1:n, Weights(w), n),
+ *     drawn in two levels: N iid segment picks are COUNTED (n_b children for segment b), the
+ *     children are laid out sorted by segment, and child j picks its ancestor iid inside its
+ *     segment.  The joint law of the ancestor multiset is exactly Multinomial(N, w); only the
+ *     (unobservable, exchangeable) order of the children differs from an unsorted draw.  The
+ *     stand-alone resample(w, N) keeps the unsorted iid order of the reference.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; never -ffast-math).
  */
@@ -57,9 +61,10 @@ typedef unsigned __int128 u128;
 #define FIX_BITS 48            /* q = rint(w~ * 2^48), w~ in [0,1] relative to segment max */
 #define MAX_SEG 8192
 #define SIM_STREAM 0xFFFFFFFFu /* stream id reserved for simulate()                       */
-#define SLOT_RESAMPLE 0u
+#define SLOT_RESAMPLE 0u       /* within-segment pick of child j                          */
 #define SLOT_NORMAL0 1u        /* slots 1..d : state normals                              */
 #define SLOT_OBS 8u            /* simulate(): observation noise                           */
+#define SLOT_COUNT 9u          /* segment pick of draw i (multi-segment filters only)     */
 
 static const double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
 static const double INV_LN2 = 0x1.71547652b82fep+0;
@@ -236,9 +241,9 @@ static void normal_pair(uint64_t seed, int64_t p, uint32_t stream, uint32_t t, u
 }
 
 /* 64 resampling bits of each member of the pair */
-static void resample_pair(uint64_t seed, int64_t p, uint32_t stream, uint32_t t, uint64_t r[2]) {
+static void resample_pair(uint64_t seed, int64_t p, uint32_t stream, uint32_t t, uint32_t slot, uint64_t r[2]) {
     uint32_t w[4];
-    draw(seed, (uint32_t)p, stream, t, SLOT_RESAMPLE, w);
+    draw(seed, (uint32_t)p, stream, t, slot, w);
     r[0] = ((uint64_t)w[1] << 32) | w[0];
     r[1] = ((uint64_t)w[3] << 32) | w[2];
 }
@@ -418,7 +423,7 @@ int orc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t seed, uint3
     }
     for (int64_t i = 0; i < ndraw; ++i) {
         uint64_t r[2];
-        resample_pair(seed, i >> 1, stream, t, r);
+        resample_pair(seed, i >> 1, stream, t, SLOT_RESAMPLE, r);
         uint64_t T = (uint64_t)(((u128)r[i & 1] * acc) >> 64);
         a[i] = upper_bound_u64(C, n, T);
     }
@@ -439,7 +444,7 @@ typedef struct {
     /* global combine */
     double K;       /* max kb */
     uint64_t* Dcum; /* [nseg] inclusive sums of Q_b = S_b >> sh_b  */
-    int* sh;        /* [nseg] sh_b = (K - kb) + SH, or 64 if the segment is out of range */
+    int64_t* cnt;   /* [nseg] children per segment of the current resampling step */
     uint64_t Dtot, Rtot;
     double logmu, ess;
 } orc_weights;
@@ -455,10 +460,10 @@ static void weights_alloc(orc_weights* W, int64_t n, int seg) {
     W->S2hi = (uint64_t*)calloc(ns, 8);
     W->S2lo = (uint64_t*)calloc(ns, 8);
     W->Dcum = (uint64_t*)calloc(ns, 8);
-    W->sh = (int*)calloc(ns, sizeof(int));
+    W->cnt = (int64_t*)calloc(ns, sizeof(int64_t));
 }
 static void weights_free(orc_weights* W) {
-    free(W->C); free(W->kb); free(W->S); free(W->S2hi); free(W->S2lo); free(W->Dcum); free(W->sh);
+    free(W->C); free(W->kb); free(W->S); free(W->S2hi); free(W->S2lo); free(W->Dcum); free(W->cnt);
 }
 
 /* normalize(logw) of particles.jl:5-15, segment by segment, then the integer combine */
@@ -496,7 +501,6 @@ static void weights_normalize(orc_weights* W, const double* logw) {
         uint64_t Rb = (sh < 64 && sh2 < 128) ? (uint64_t)(s2 >> sh2) : 0;
         D += Qb; R += Rb;
         W->Dcum[b] = D;
-        W->sh[b] = sh;
     }
     W->Dtot = D; W->Rtot = R;
     double Dd = (double)D * bits2d((uint64_t)(1023 + W->SH - 48) << 52);
@@ -505,16 +509,33 @@ static void weights_normalize(orc_weights* W, const double* logw) {
     W->ess = R ? Dd * Dd / Rd : 0.0;
 }
 
-/* ancestor of particle i: one 64-bit draw, two-level inverse CDF, integers only */
-static int64_t weights_draw(const orc_weights* W, uint64_t r, int64_t i) {
-    if (W->Dtot == 0) return i;                                  /* collapsed filter: identity */
-    u128 P = (u128)r * W->Dtot;
-    uint64_t T1 = (uint64_t)(P >> 64), lo = (uint64_t)P;
-    int64_t b = upper_bound_u64(W->Dcum, W->nseg, T1);
-    uint64_t rho = T1 - (b ? W->Dcum[b - 1] : 0);                /* uniform on [0, Q_b)        */
-    int s = W->sh[b];
-    uint64_t T2 = s ? (rho << s) | (lo >> (64 - s)) : rho;       /* uniform on [0, Q_b << s)   */
-    return b * W->seg + upper_bound_u64(W->C + (size_t)b * W->seg, W->seg, T2);
+/* a = resample(weights): ancestors of all n children, exactly Multinomial(n, w), children sorted
+ * by ancestor segment.  (seed, stream, t) select the Philox counters. */
+static void weights_resample(orc_weights* W, uint64_t seed, uint32_t stream, uint32_t t, int64_t* a) {
+    const int64_t n = W->n;
+    uint64_t r[2];
+    if (W->Dtot == 0) {                                          /* collapsed filter: identity */
+        for (int64_t i = 0; i < n; ++i) a[i] = i;
+        return;
+    }
+    if (W->nseg > 1) {                                           /* level 1: count the segment picks */
+        for (int b = 0; b < W->nseg; ++b) W->cnt[b] = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (!(i & 1)) resample_pair(seed, i >> 1, stream, t, SLOT_COUNT, r);
+            uint64_t T1 = (uint64_t)(((u128)r[i & 1] * W->Dtot) >> 64);
+            W->cnt[upper_bound_u64(W->Dcum, W->nseg, T1)] += 1;
+        }
+    } else {
+        W->cnt[0] = n;
+    }
+    int b = 0;
+    int64_t end = W->cnt[0];                                     /* children [.., end) belong to segment b */
+    for (int64_t j = 0; j < n; ++j) {                            /* level 2: iid pick inside the segment */
+        while (j >= end) end += W->cnt[++b];
+        if (!(j & 1)) resample_pair(seed, j >> 1, stream, t, SLOT_RESAMPLE, r);
+        uint64_t T2 = (uint64_t)(((u128)r[j & 1] * W->S[b]) >> 64);
+        a[j] = (int64_t)b * W->seg + upper_bound_u64(W->C + (size_t)b * W->seg, W->seg, T2);
+    }
 }
 
 /* dense normalised weights w_i (what the reference's normalize returns as `w`) */
@@ -600,11 +621,7 @@ double orc_bootstrap_filter_step(orc_filter* f, double y, double* ess) {
     const int d = f->model.d;
     const int64_t n = f->n;
     double z[3], xpi[3], xi[3], zp[3][2];
-    uint64_t r[2];
-    for (int64_t i = 0; i < n; ++i) {                           /* a = resample(weights)            */
-        if (!(i & 1)) resample_pair(f->seed, i >> 1, f->stream, f->t, r);
-        f->a[i] = weights_draw(&f->W, r[i & 1], i);
-    }
+    weights_resample(&f->W, f->seed, f->stream, f->t, f->a);    /* a = resample(weights)            */
     for (int k = 0; k < d; ++k)                                 /* xp = deepcopy(x[a])              */
         for (int64_t i = 0; i < n; ++i) f->xp[(size_t)k * n + i] = f->x[(size_t)k * n + f->a[i]];
     for (int64_t i = 0; i < n; ++i) {

@@ -110,6 +110,21 @@ static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) 
     }
     return hipErrorInvalidValue;
 }
+namespace smc {
+hipError_t launch_count(const FilterView& v, int cur, uint32_t t, int emit_prev, hipStream_t s) {
+    constexpr int TH = 256;
+    const int64_t npairs = (v.n + 1) >> 1;
+    int64_t ncw = npairs / 2048;
+    ncw = ncw < 1 ? 1 : (ncw > 1024 ? 1024 : ncw);
+    hipLaunchKernelGGL((k_count<TH>), dim3((unsigned)ncw, v.ntheta), dim3(TH), count_lds_bytes(v.nseg_p2, TH), s, v, cur, t,
+                       emit_prev);
+    return hipGetLastError();
+}
+}  // namespace smc
+static hipError_t do_count(smc_filter_s* h, uint32_t t, int emit_prev) {
+    if (h->v.nseg <= 1) return hipSuccess;   // single segment: every child picks in segment 0
+    return launch_count(h->v, h->cur, t, emit_prev, h->stream);
+}
 static hipError_t do_resident(smc_filter_s* h, int T) {
     switch (h->model) {
     case MODEL_LG1D: return launch_resident<MODEL_LG1D>(h->v, T, h->d_recs, h->stream);
@@ -194,6 +209,10 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
         TRY(hipMemsetAsync(v.x[b], 0, np * (size_t)d * 8, h->stream));
         TRY(hipMemsetAsync(v.C[b], 0, np * 8, h->stream));
     }
+    for (int b = 0; b < 2; ++b) {
+        TRY(dalloc(&v.cnt[b], ns));
+        TRY(hipMemsetAsync(v.cnt[b], 0, ns * 4, h->stream));
+    }
     if (flags & SMC_FLAG_ANCESTORS) TRY(dalloc(&v.anc, np));
     TRY(dalloc(&v.logZ, nt));
     TRY(dalloc(&v.last_logmu, nt));
@@ -218,7 +237,7 @@ extern "C" int smc_destroy(smc_handle h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     FilterView& v = h->v;
     for (int b = 0; b < 2; ++b) {
-        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]);
+        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]); (void)hipFree(v.cnt[b]);
     }
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
@@ -334,6 +353,7 @@ extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
     HIPCHK(hipSetDevice(h->device));
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(do_count(h, h->t, h->emitted ? 0 : 1));
     HIPCHK(do_step(h, h->t, h->emitted ? 0 : 1, y_t));
     h->cur ^= 1; h->t += 1; h->emitted = false;
     int rc = emit_if_needed(h);
@@ -371,6 +391,7 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
         HIPCHK(do_init(h, y[0]));
         h->t = 1; h->inited = true; h->emitted = false;
         for (int64_t t = 1; t < T; ++t) {
+            HIPCHK(do_count(h, (uint32_t)t, 1));
             HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
             h->cur ^= 1; h->t += 1;
         }
@@ -405,6 +426,7 @@ extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, in
     int k = 0;
     for (int64_t t = 1; t < T; ++t) {
         const bool s = k < nsample && ((t - 1) % stride) == stride / 2;
+        HIPCHK(do_count(h, (uint32_t)t, 1));
         if (s) HIPCHK(hipEventRecord(e0[k], h->stream));
         HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
         if (s) { HIPCHK(hipEventRecord(e1[k], h->stream)); ++k; }

@@ -13,9 +13,12 @@
 // q_i = rint(p_i * 2^(48 + k_i - kb)) (uint64, exact, order independent; exp(logw_i) = p_i 2^k_i,
 // kb = max k_i) plus its record (kb, S = sum q, S2 = sum q^2 as 128 bit).  The next launch's
 // prologue turns the records of all segments of the filter into a second integer table (Dcum,
-// by shifts only) in LDS; a particle then draws its ancestor with ONE 64-bit Philox draw:
-// table search in LDS, then segment search in C.  All searches of a thread advance level by
-// level together (2*NP independent loads in flight per lane per level).
+// by shifts only) in LDS.  resample() is exactly multinomial but SEGMENT-SORTED so that a
+// workgroup's children read the same few ancestor segments (L1/L2-resident, near-streaming):
+//   k_count  draws the N iid segment picks and histograms them (integer atomics: order-free)
+//   k_step   lays the children out by segment (prefix sums of the counts) and lets child j pick
+//            iid inside its segment: search in C_b, gather x[a], propagate, weigh, normalise.
+// All searches of a thread advance level by level together (2*NP independent loads in flight).
 #pragma once
 #include "smc_spec.h"
 
@@ -37,6 +40,7 @@ struct FilterView {
     uint64_t* segS[2];
     uint64_t* segS2hi[2];
     uint64_t* segS2lo[2];
+    uint32_t* cnt[2];        // [ntheta][nseg] children per segment, double-buffered by step parity
     int32_t* anc;            // [ntheta][npad] or nullptr
     double* logZ;            // [ntheta]
     double* last_logmu;      // [ntheta]  (logmu, ess, K, D) of the most recently emitted weights
@@ -363,7 +367,119 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
             *reinterpret_cast<int2*>(v.anc + (size_t)th * v.npad + i0) = o;
         }
     }
+    if (sb == 0) {
+        for (int b = tid; b < v.nseg; b += THREADS) {
+            v.cnt[0][(size_t)th * v.nseg + b] = 0;
+            v.cnt[1][(size_t)th * v.nseg + b] = 0;
+        }
+    }
     segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_count : level 1 of resample(weights) for multi-segment filters.  grid (ncw, ntheta).
+// Draw i in [0, n) picks segment b_i ~ Categorical(Q / Dtot) (64-bit Philox draw, integer
+// table in LDS); n_b = #{i : b_i = b} is accumulated with integer atomics, so the counts do not
+// depend on the order of arrival.  Workgroup 0 of each filter also emits (logmu, ess) of the
+// weights being resampled (the return value of the previous normalize()).
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32_t t, int emit_prev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int th = blockIdx.y, tid = threadIdx.x;
+    const TableLds L = carve(smem, v.nseg_p2);
+    unsigned int* hist = (unsigned int*)(L.scr + scr_words(THREADS, 1));   // [nseg_p2]
+    for (int b = tid; b < v.nseg_p2; b += THREADS) hist[b] = 0;
+    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u);
+    if (Dtot == 0) return;   // collapsed filter: counts stay 0, k_step falls back to identity
+    const uint32_t stream = v.stream[th];
+    const int64_t npairs = (v.n + 1) >> 1;
+    const int64_t per = (npairs + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < npairs) ? p0 + per : npairs;
+    for (int64_t pb = p0; pb < p1; pb += 2 * THREADS) {
+        // two pairs (four draws) per thread per trip: independent LDS searches in flight
+        uint64_t T1[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t p = pb + tid + u * THREADS;
+            const u32x4 rw = draw(v.seed, (uint32_t)p, stream, t, SLOT_COUNT);
+            uint64_t lo;
+            mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], Dtot, T1[2 * u], lo);
+            mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], Dtot, T1[2 * u + 1], lo);
+            ok[2 * u] = p < p1 && 2 * p < v.n;
+            ok[2 * u + 1] = p < p1 && 2 * p + 1 < v.n;
+        }
+        int pos[4] = {0, 0, 0, 0};
+        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pos[i] += (L.Dcum[pos[i] + s - 1] <= T1[i]) ? s : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ok[i]) atomicAdd(&hist[pos[i]], 1u);
+    }
+    __syncthreads();
+    unsigned int* out = v.cnt[t & 1] + (size_t)th * v.nseg;
+    for (int b = tid; b < v.nseg; b += THREADS) {
+        const unsigned int c = hist[b];
+        if (c) atomicAdd(&out[b], c);
+    }
+}
+__host__ __device__ inline size_t count_lds_bytes(int nseg_p2, int threads) {
+    return table_lds_bytes(nseg_p2, threads, 1) + (size_t)nseg_p2 * 4;
+}
+
+// Offsets prologue of k_step (multi-segment): inclusive prefix sums of the children counts and
+// the segment sums S_b into LDS.  Returns the total number of children (0 = collapsed filter).
+struct OffsLds {
+    unsigned int* off;  // [nseg_p2] inclusive sums of n_b
+    uint64_t* S;        // [nseg_p2]
+    uint64_t* scr;
+};
+__host__ __device__ inline size_t offs_lds_bytes(int nseg_p2, int threads, int np) {
+    return (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;
+}
+__device__ __forceinline__ OffsLds carve_offs(char* smem, int nseg_p2) {
+    OffsLds o;
+    o.S = (uint64_t*)smem;
+    o.off = (unsigned int*)(smem + (size_t)nseg_p2 * 8);
+    o.scr = (uint64_t*)(smem + (size_t)nseg_p2 * 16);
+    return o;
+}
+template <int THREADS>
+__device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, int cur, int th, uint32_t t, const OffsLds& L) {
+    constexpr int NW = THREADS / WAVE;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const unsigned int* cn = v.cnt[t & 1] + (size_t)th * v.nseg;
+    const uint64_t* sS = v.segS[cur] + (size_t)th * v.nseg;
+    const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1;
+    uint64_t run = 0;
+    if (tid * E < v.nseg_p2) {
+        for (int e = 0; e < E; ++e) {
+            const int b = tid * E + e;
+            const bool in = b < v.nseg;
+            run += in ? cn[b] : 0u;
+            L.off[b] = (unsigned int)run;
+            L.S[b] = in ? sS[b] : 0;
+        }
+    }
+    const uint64_t incl = wave_incl_scan(run, lane);
+    uint64_t* wt = L.scr;
+    if (lane == WAVE - 1) wt[wave] = incl;
+    __syncthreads();
+    uint64_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const uint64_t x = wt[w];
+        off += (w < wave) ? x : 0;
+        tot += x;
+    }
+    const unsigned int excl = (unsigned int)(off + incl - run);
+    if (tid * E < v.nseg_p2)
+        for (int e = 0; e < E; ++e) L.off[tid * E + e] += excl;
+    __syncthreads();
+    return (unsigned int)tot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,55 +499,60 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int sb = blockIdx.x, th = blockIdx.y, tid = threadIdx.x;
     const int nxt = cur ^ 1;
-    const TableLds L = carve(smem, v.nseg_p2);
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
     const double y = v.y ? v.y[t] : yval;
     const int64_t seg0 = (int64_t)sb * SEG;
+    uint64_t* scr;
 
-    uint64_t Dtot = 0;
-    if (MULTI || (emit_prev && sb == 0)) {
-        Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && sb == 0, t == 1u, t - 1u);
+    // alive = some weight is positive; otherwise the filter collapsed and ancestors are the identity
+    uint64_t alive;
+    uint64_t Sseg[NQ];
+    int bseg[NQ];
+    if (MULTI) {
+        const OffsLds L = carve_offs(smem, v.nseg_p2);
+        scr = L.scr;
+        alive = offsets_prologue<THREADS>(v, cur, th, t, L);
+        if (sb == 0) {   // the counts of step t+1 accumulate into the other buffer: clear it
+            for (int b = tid; b < v.nseg; b += THREADS) v.cnt[(t + 1) & 1][(size_t)th * v.nseg + b] = 0;
+        }
+        // child j belongs to the first segment b with off[b] > j
+        int pos[NQ];
+        unsigned int jj[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            jj[i] = (unsigned int)(seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1));
+            pos[i] = 0;
+        }
+        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) pos[i] += (L.off[pos[i] + s - 1] <= jj[i]) ? s : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            bseg[i] = pos[i] < v.nseg ? pos[i] : v.nseg - 1;
+            Sseg[i] = L.S[bseg[i]];
+        }
+    } else {
+        const TableLds L = carve(smem, v.nseg_p2);
+        scr = L.scr;
+        if (emit_prev && sb == 0) table_prologue<THREADS>(v, cur, th, L, true, t == 1u, t - 1u);
+        alive = v.segS[cur][(size_t)th * v.nseg];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) { bseg[i] = 0; Sseg[i] = alive; }
     }
-    if (!MULTI) Dtot = v.segS[cur][(size_t)th * v.nseg];   // SH = 0, sh = 0: the table is (S_0)
     const uint64_t* Cprev = v.C[cur] + (size_t)th * v.npad;
     const double* xprev = v.x[cur];
 
-    // ---- a = resample(weights): all NQ draws of this thread advance together -----------------
+    // ---- a = resample(weights), level 2: iid pick inside the child's segment -------------------
     uint64_t T2[NQ];
-    int bseg[NQ];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
         const u32x4 rw = draw(v.seed, pg, stream, t, SLOT_RESAMPLE);
-        T2[2 * k] = ((uint64_t)rw.v[1] << 32) | rw.v[0];       // holds r for now
-        T2[2 * k + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
-    }
-    if (MULTI) {
-        uint64_t T1[NQ], lo[NQ];
-        int pos[NQ];
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) { mul64wide(T2[i], Dtot, T1[i], lo[i]); pos[i] = 0; }
-        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) pos[i] += (L.Dcum[pos[i] + s - 1] <= T1[i]) ? s : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int b = pos[i] < v.nseg ? pos[i] : v.nseg - 1;   // in range whenever Dtot > 0
-            const uint64_t rho = T1[i] - (b ? L.Dcum[b - 1] : 0);
-            const int s = L.sh[b] & 63;
-            T2[i] = s ? (rho << s) | (lo[i] >> (64 - s)) : rho;
-            bseg[i] = b;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            uint64_t hi, lo;
-            mul64wide(T2[i], Dtot, hi, lo);
-            T2[i] = hi;
-            bseg[i] = 0;
-        }
+        uint64_t lo;
+        mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], Sseg[2 * k], T2[2 * k], lo);
+        mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], Sseg[2 * k + 1], T2[2 * k + 1], lo);
     }
     int pos[NQ];
     const uint64_t* Cb[NQ];
@@ -451,8 +572,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     for (int i = 0; i < NQ; ++i) {
         const int64_t own = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
         int64_t a = (int64_t)bseg[i] * SEG + pos[i];
-        a = Dtot ? a : own;                 // collapsed filter: identity
-        a = a < v.n ? a : v.n - 1;          // cannot happen when Dtot > 0 (padding has q = 0)
+        a = alive ? a : own;                // collapsed filter: identity
+        a = a < v.n ? a : v.n - 1;          // only masked children (j >= n) can land there
         anc[i] = a;
 #pragma unroll
         for (int c = 0; c < D; ++c) xp[i][c] = xprev[((size_t)c * v.ntheta + th) * v.npad + a];
@@ -490,7 +611,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             *reinterpret_cast<int2*>(v.anc + (size_t)th * v.npad + i0) = o;
         }
     }
-    segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, L.scr);
+    segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
 }
 
 // ---------------------------------------------------------------------------------------------

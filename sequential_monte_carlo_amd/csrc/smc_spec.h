@@ -24,9 +24,10 @@ constexpr int NPARAM = 8;        // padded row length of raw / derived parameter
 constexpr int FIX_BITS = 48;     // q = rint(p * 2^(48 + k - kb)),  exp(logw) = p * 2^k
 constexpr int MAX_SEG = 8192;
 constexpr uint32_t SIM_STREAM = 0xFFFFFFFFu;
-constexpr uint32_t SLOT_RESAMPLE = 0u;
-constexpr uint32_t SLOT_NORMAL0 = 1u;
-constexpr uint32_t SLOT_OBS = 8u;
+constexpr uint32_t SLOT_RESAMPLE = 0u;   // within-segment pick of child j
+constexpr uint32_t SLOT_NORMAL0 = 1u;    // slots 1..d: state normals
+constexpr uint32_t SLOT_OBS = 8u;        // simulate(): observation noise
+constexpr uint32_t SLOT_COUNT = 9u;      // segment pick of draw i (multi-segment filters)
 
 constexpr double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
 constexpr double INV_LN2 = 0x1.71547652b82fep+0;
