@@ -74,6 +74,10 @@ int smc_get_logZ(smc_handle h, double* logZ /*[n_theta]*/, double* ess /*[n_thet
 /* resample!(smc) of the OUTER sampler (src/smc_samplers.jl:74-84): filter slot m <- slot a[m]
  * (value copy of x cloud, weights and logZ; stream ids stay with the slot). */
 int smc_permute(smc_handle h, const int32_t* a /*[n_theta]*/);
+/* PMMH accept step of rejuvenate! (src/smc_samplers.jl:129-136): for every m with mask[m] != 0 the
+ * filter state of slot m (x cloud, weights, logZ) is overwritten by slot m of `src` (the proposal
+ * filters, same geometry).  Value copy on the device; streams and parameters are not copied. */
+int smc_copy_from(smc_handle dst, smc_handle src, const uint8_t* mask /*[n_theta]*/);
 
 /* raw fixed-point weight state (tests): C [n_theta][nseg*seg], m/S/S2hi/S2lo [n_theta][nseg] */
 int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo);

@@ -51,6 +51,8 @@ def lib():
         L.orc_filter_create.argtypes = [C.c_int, _dp, C.c_int64, C.c_int, C.c_uint64, C.c_uint32]
         L.orc_filter_destroy.argtypes = [C.c_void_p]
         L.orc_filter_reseed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.orc_filter_set_params.argtypes = [C.c_void_p, _dp]
+        L.orc_filter_copy_state.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_bootstrap_filter.restype = C.c_double
         L.orc_bootstrap_filter.argtypes = [C.c_void_p, C.c_double]
         L.orc_bootstrap_filter_step.restype = C.c_double
@@ -157,6 +159,13 @@ class Filter:
 
     def reseed(self, seed, stream=0):
         lib().orc_filter_reseed(self._h, seed, stream)
+
+    def set_params(self, raw):
+        raw = np.ascontiguousarray(raw, dtype=np.float64)
+        assert lib().orc_filter_set_params(self._h, _d(raw)) == 0
+
+    def copy_state_from(self, src):
+        assert lib().orc_filter_copy_state(self._h, src._h) == 0
 
     def bootstrap_filter(self, y):
         return lib().orc_bootstrap_filter(self._h, float(y))

@@ -596,6 +596,29 @@ void orc_filter_destroy(orc_filter* f) {
     free(f);
 }
 
+/* smc.model(theta[m]) changed (PMMH accept / per-step parameter refresh): same particles, new parameters */
+int orc_filter_set_params(orc_filter* f, const double* raw) { return model_init(&f->model, f->model.id, raw); }
+
+/* value copy of the filter STATE (x cloud, weights, t) from src into dst; dst keeps its own seed,
+ * stream and parameters (resample!(smc) smc_samplers.jl:74-84 and the PMMH accept :130-133) */
+int orc_filter_copy_state(orc_filter* dst, const orc_filter* src) {
+    if (dst->n != src->n || dst->W.seg != src->W.seg || dst->model.d != src->model.d) return -1;
+    const size_t n = (size_t)dst->n, d = (size_t)dst->model.d, ns = (size_t)dst->W.nseg;
+    memcpy(dst->x, src->x, 8 * d * n);
+    memcpy(dst->logw, src->logw, 8 * n);
+    memcpy(dst->a, src->a, 8 * n);
+    memcpy(dst->W.C, src->W.C, 8 * ns * (size_t)dst->W.seg);
+    memcpy(dst->W.kb, src->W.kb, 8 * ns);
+    memcpy(dst->W.S, src->W.S, 8 * ns);
+    memcpy(dst->W.S2hi, src->W.S2hi, 8 * ns);
+    memcpy(dst->W.S2lo, src->W.S2lo, 8 * ns);
+    memcpy(dst->W.Dcum, src->W.Dcum, 8 * ns);
+    dst->W.K = src->W.K; dst->W.Dtot = src->W.Dtot; dst->W.Rtot = src->W.Rtot;
+    dst->W.logmu = src->W.logmu; dst->W.ess = src->W.ess;
+    dst->t = src->t;
+    return 0;
+}
+
 void orc_filter_reseed(orc_filter* f, uint64_t seed, uint32_t stream) { f->seed = seed; f->stream = stream; f->t = 0; }
 
 /* bootstrap_filter(N, y, model)  particles.jl:87-105  -> logmu */

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsmchip.so")
+LIB_PATH = os.environ.get("SMC_LIB") or os.path.join(_HERE, "lib", "libsmchip.so")   # SMC_LIB: profiling builds
 
 MODEL_LG1D, MODEL_SV1D, MODEL_UCSV3D = 1, 2, 3
 FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
@@ -17,7 +17,7 @@ FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
 # every symbol include/smc_hip.h declares
 EXPORTS = [
     "smc_create", "smc_destroy", "smc_set_params", "smc_set_streams", "smc_reseed", "smc_init", "smc_step",
-    "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_get_weights_raw", "smc_get_geometry",
+    "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_copy_from", "smc_get_weights_raw", "smc_get_geometry",
     "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_normalize", "smc_resample", "smc_simulate", "smc_model_dim",
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
     "smc_host_box_muller", "smc_device_math", "smc_last_error", "smc_version",
@@ -58,6 +58,7 @@ def lib():
     L.smc_get_state.argtypes = [h, _dp, _dp, _i32p]
     L.smc_get_logZ.argtypes = [h, _dp, _dp]
     L.smc_permute.argtypes = [h, _i32p]
+    L.smc_copy_from.argtypes = [h, h, C.POINTER(C.c_uint8)]
     L.smc_get_weights_raw.argtypes = [h, _u64p, _dp, _u64p, _u64p, _u64p]
     L.smc_get_geometry.argtypes = [h, _ip, _ip, _ip, _ip]
     L.smc_last_elapsed_ms.argtypes = [h, _dp]
@@ -208,6 +209,11 @@ class Handle:
         a = np.ascontiguousarray(a, dtype=np.int32)
         assert a.size == self.n_theta
         check(lib().smc_permute(self._h, a.ctypes.data_as(_i32p)))
+
+    def copy_from(self, src, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.size == self.n_theta
+        check(lib().smc_copy_from(self._h, src._h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
 
     def weights_raw(self):
         npad = self.nseg * self.seg

@@ -45,6 +45,32 @@ __global__ void k_permute(FilterView v, int cur, int d, const int32_t* a, const 
     if (i == 0) v.logZ[th] = logZ_src[src];
 }
 
+// accept step: slot th of dst <- slot th of src where mask[th]   grid (blocks, ntheta)
+__global__ void k_copy_slots(FilterView dst, int dcur, FilterView src, int scur, int d, const unsigned char* mask) {
+    const int th = blockIdx.y;
+    if (!mask[th]) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < dst.npad) {
+        for (int c = 0; c < d; ++c)
+            dst.x[dcur][((size_t)c * dst.ntheta + th) * dst.npad + i] = src.x[scur][((size_t)c * src.ntheta + th) * src.npad + i];
+        dst.C[dcur][(size_t)th * dst.npad + i] = src.C[scur][(size_t)th * src.npad + i];
+    }
+    if (i < dst.nseg) {
+        const size_t o = (size_t)th * dst.nseg + i;
+        dst.segk[dcur][o] = src.segk[scur][o];
+        dst.segS[dcur][o] = src.segS[scur][o];
+        dst.segS2hi[dcur][o] = src.segS2hi[scur][o];
+        dst.segS2lo[dcur][o] = src.segS2lo[scur][o];
+    }
+    if (i == 0) {
+        dst.logZ[th] = src.logZ[th];
+        dst.last_logmu[th] = src.last_logmu[th];
+        dst.last_ess[th] = src.last_ess[th];
+        dst.last_K[th] = src.last_K[th];
+        dst.last_D[th] = src.last_D[th];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // stand-alone A1 / A2 (outer theta-level reweight / resample; n <= a few thousand): one
 // workgroup, single level, all integer sums.

@@ -15,6 +15,9 @@
 using namespace smc;
 
 static thread_local std::string g_err;
+#ifdef SMC_ABLATE
+static int h_abl_tmp = 0;
+#endif
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -69,7 +72,7 @@ bool geo_default(int seg, Geo& g) {
     case 256: g = {128, 1}; return true;
     case 512: g = {256, 1}; return true;
     case 1024: g = {256, 2}; return true;
-    case 2048: g = {256, 4}; return true;
+    case 2048: g = {512, 2}; return true;
     case 4096: g = {512, 4}; return true;
     case 8192: g = {1024, 4}; return true;
     }
@@ -112,9 +115,9 @@ static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) 
 }
 namespace smc {
 hipError_t launch_count(const FilterView& v, int cur, uint32_t t, int emit_prev, hipStream_t s) {
-    constexpr int TH = 256;
+    constexpr int TH = 1024;   // fat workgroups: the table prologue is paid once per workgroup
     const int64_t npairs = (v.n + 1) >> 1;
-    int64_t ncw = npairs / 2048;
+    int64_t ncw = (npairs + 2 * TH - 1) / (2 * TH);   // one trip (2 pairs = 4 draws) per thread
     ncw = ncw < 1 ? 1 : (ncw > 1024 ? 1024 : ncw);
     hipLaunchKernelGGL((k_count<TH>), dim3((unsigned)ncw, v.ntheta), dim3(TH), count_lds_bytes(v.nseg_p2, TH), s, v, cur, t,
                        emit_prev);
@@ -158,6 +161,9 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     if (seg == 0) seg = smc_auto_seg(n_x);
     Geo g;
     if (!geo_default(seg, g)) return fail(SMC_EINVAL, "smc_create: seg must be a power of two in [256,8192]");
+#ifdef SMC_ABLATE
+    if (const char* e = getenv("SMC_ABL")) h_abl_tmp = atoi(e);
+#endif
     if (const char* e = getenv("SMC_NP")) {   // tuning knob: particle pairs per thread (1, 2 or 4)
         Geo g2;
         if (geo_valid(seg, atoi(e), g2)) g = g2;
@@ -180,6 +186,9 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     while (p2 < v.nseg) p2 <<= 1;
     v.nseg_p2 = p2;
     v.SH = table_shift_extra(v.npad);
+#ifdef SMC_ABLATE
+    v.abl = h_abl_tmp;
+#endif
     h->resident_ok = (v.nseg == 1) && !(flags & SMC_FLAG_NO_RESIDENT);
 
     const size_t np = (size_t)v.ntheta * (size_t)v.npad, ns = (size_t)v.ntheta * (size_t)v.nseg, nt = (size_t)v.ntheta;
@@ -509,6 +518,29 @@ extern "C" int smc_permute(smc_handle h, const int32_t* a) {
     HIPCHK(do_finalize(h, 0, h->t - 1));
     HIPCHK(hipMemcpyAsync(v.logZ, h->d_logZ_tmp, (size_t)v.ntheta * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return SMC_OK;
+}
+
+extern "C" int smc_copy_from(smc_handle dst, smc_handle src, const uint8_t* mask) {
+    if (!dst || !src || !mask) return fail(SMC_EINVAL, "smc_copy_from: NULL argument");
+    if (dst == src) return fail(SMC_EINVAL, "smc_copy_from: dst and src are the same handle");
+    if (!dst->inited || !src->inited) return fail(SMC_ESTATE, "smc_copy_from: filter not initialised");
+    const FilterView &a = dst->v, &b = src->v;
+    if (dst->model != src->model || a.n != b.n || a.seg != b.seg || a.ntheta != b.ntheta || dst->device != src->device)
+        return fail(SMC_EINVAL, "smc_copy_from: handles differ in model, geometry or device");
+    HIPCHK(hipSetDevice(dst->device));
+    int rc = emit_if_needed(dst);
+    if (rc) return rc;
+    rc = emit_if_needed(src);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(src->stream));
+    unsigned char* d_mask = reinterpret_cast<unsigned char*>(dst->d_perm);   // n_theta bytes fit in n_theta int32
+    HIPCHK(hipMemcpyAsync(d_mask, mask, (size_t)a.ntheta, hipMemcpyHostToDevice, dst->stream));
+    hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)((a.npad + 255) / 256), a.ntheta), dim3(256), 0, dst->stream, a, dst->cur,
+                       b, src->cur, dst->d, d_mask);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(dst->stream));
+    dst->t = src->t;   // the accepted filters have seen the same observations
     return SMC_OK;
 }
 

@@ -50,7 +50,14 @@ struct FilterView {
     double* trace_logmu;     // [T][ntheta] or nullptr
     double* trace_ess;       // [T][ntheta] or nullptr
     const double* y;         // [T] on device (log_likelihood) or nullptr
+    int abl;                 // ablation mask: always 0 in the product (profiling builds only, -DSMC_ABLATE)
 };
+
+#ifdef SMC_ABLATE
+#define SMC_ABL(v, bit) (((v).abl >> (bit)) & 1)
+#else
+#define SMC_ABL(v, bit) 0
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // wave / block primitives (wave64)
@@ -111,7 +118,8 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-// max over the workgroup; every thread gets the result. `red` : NW doubles of LDS.
+// max over the workgroup; every thread gets the result. `red` : NW doubles of LDS that nobody
+// writes again before the workgroup's next barrier (ONE barrier here).
 template <int THREADS>
 __device__ __forceinline__ double block_max(double v, double* red) {
     constexpr int NW = THREADS / WAVE;
@@ -122,7 +130,6 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     double r = red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) r = red[w] > r ? red[w] : r;
-    __syncthreads();
     return r;
 }
 
@@ -135,7 +142,7 @@ struct TableLds {
     uint64_t* scr;   // scratch
 };
 __host__ __device__ inline size_t scr_words(int threads, int np) {
-    return (size_t)((np + 2 > 4 ? np + 2 : 4) * (threads / WAVE) + 8);
+    return (size_t)((np + 3 > 4 ? np + 3 : 4) * (threads / WAVE) + 8);   // [red | wave totals ...]
 }
 __host__ __device__ inline size_t table_lds_bytes(int nseg_p2, int threads, int np) {
     return (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;   // sh padded to 8 B per entry
@@ -267,8 +274,8 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
         incl[k] = wave_incl_scan(ps[k], lane);
     }
     s2 = wave_sum128(s2);
-    uint64_t* wtot = scr;                 // [NP][NW]
-    uint64_t* w2 = scr + NP * NW;         // [2][NW]
+    uint64_t* wtot = scr + NW;            // [NP][NW]   (scr[0..NW) is block_max's)
+    uint64_t* w2 = scr + (NP + 1) * NW;   // [2][NW]
     if (lane == WAVE - 1) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) wtot[k * NW + wave] = incl[k];
@@ -465,7 +472,7 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
         }
     }
     const uint64_t incl = wave_incl_scan(run, lane);
-    uint64_t* wt = L.scr;
+    uint64_t* wt = L.scr + 2 * NW;   // not the region block_max / the epilogue's first writes use
     if (lane == WAVE - 1) wt[wave] = incl;
     __syncthreads();
     uint64_t off = 0, tot = 0;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     if (MULTI) {
         const OffsLds L = carve_offs(smem, v.nseg_p2);
         scr = L.scr;
-        alive = offsets_prologue<THREADS>(v, cur, th, t, L);
+        alive = SMC_ABL(v, 5) ? 1u : offsets_prologue<THREADS>(v, cur, th, t, L);
         if (sb == 0) {   // the counts of step t+1 accumulate into the other buffer: clear it
             for (int b = tid; b < v.nseg; b += THREADS) v.cnt[(t + 1) & 1][(size_t)th * v.nseg + b] = 0;
         }
@@ -532,6 +539,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         for (int i = 0; i < NQ; ++i) {
             bseg[i] = pos[i] < v.nseg ? pos[i] : v.nseg - 1;
             Sseg[i] = L.S[bseg[i]];
+            if (SMC_ABL(v, 5)) { bseg[i] = sb; Sseg[i] = 1ull << 50; }
         }
     } else {
         const TableLds L = carve(smem, v.nseg_p2);
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
-        const u32x4 rw = draw(v.seed, pg, stream, t, SLOT_RESAMPLE);
+        const u32x4 rw = SMC_ABL(v, 3) ? u32x4{{pg * 2654435761u, pg ^ t, pg * 40503u, ~pg}} : draw(v.seed, pg, stream, t, SLOT_RESAMPLE);
         uint64_t lo;
         mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], Sseg[2 * k], T2[2 * k], lo);
         mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], Sseg[2 * k + 1], T2[2 * k + 1], lo);
@@ -558,13 +566,18 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     const uint64_t* Cb[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) { pos[i] = 0; Cb[i] = Cprev + (size_t)bseg[i] * SEG; }
+    if (SMC_ABL(v, 0)) {
 #pragma unroll
-    for (int s = SEG >> 1; s >= 1; s >>= 1) {
-        uint64_t val[NQ];
+        for (int i = 0; i < NQ; ++i) pos[i] = (int)(T2[i] & (SEG - 1));
+    } else {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) val[i] = Cb[i][pos[i] + s - 1];
+        for (int s = SEG >> 1; s >= 1; s >>= 1) {
+            uint64_t val[NQ];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
+            for (int i = 0; i < NQ; ++i) val[i] = Cb[i][pos[i] + s - 1];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
+        }
     }
     int64_t anc[NQ];
     double xp[NQ][D];
@@ -576,7 +589,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         a = a < v.n ? a : v.n - 1;          // only masked children (j >= n) can land there
         anc[i] = a;
 #pragma unroll
-        for (int c = 0; c < D; ++c) xp[i][c] = xprev[((size_t)c * v.ntheta + th) * v.npad + a];
+        for (int c = 0; c < D; ++c) xp[i][c] = SMC_ABL(v, 1) ? 0.25 * (double)(a & 7) : xprev[((size_t)c * v.ntheta + th) * v.npad + a];
     }
 
     // ---- x[i] = rand(transition(xp[i])); logw[i] = logpdf(observation(x[i]), y) ---------------
@@ -587,7 +600,11 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         const uint32_t pg = (uint32_t)(i0 >> 1);
         double z[D][2], xn[2][D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[c][0], z[c][1]);
+        for (int c = 0; c < D; ++c) {
+            if (SMC_ABL(v, 2)) { z[c][0] = 1e-3 * (double)(pg & 1023); z[c][1] = -z[c][0]; }
+            else if (SMC_ABL(v, 6)) { const u32x4 w4 = draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c); z[c][0] = 1e-9 * (double)w4.v[0]; z[c][1] = 1e-9 * (double)w4.v[2]; }
+            else box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[c][0], z[c][1]);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             double zz[D];
@@ -610,6 +627,13 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             o.y = (int)anc[2 * k + 1];
             *reinterpret_cast<int2*>(v.anc + (size_t)th * v.npad + i0) = o;
         }
+    }
+    if (SMC_ABL(v, 4)) {   // keep lw alive, skip the normalisation
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) acc += lw[k][0] + lw[k][1];
+        if (acc == 1.2345) v.logZ[th] = acc;
+        return;
     }
     segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
 }

@@ -1,0 +1,98 @@
+"""The few priors the reference's examples use (README.md:81-85, examples/inflation_example.jl:33-37,
+234-239), with the three operations the samplers need: rand, logpdf, insupport
+(src/smc_samplers.jl:38,116,123).  Host-side numpy; O(n_theta) work per stage."""
+import math
+
+import numpy as np
+from scipy.special import ndtr, ndtri
+
+
+class Normal:
+    def __init__(self, mu=0.0, sigma=1.0):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def rand(self, rng):
+        return self.mu + self.sigma * rng.standard_normal()
+
+    def logpdf(self, x):
+        z = (x - self.mu) / self.sigma
+        return -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma)
+
+    def insupport(self, x):
+        return math.isfinite(x)
+
+
+class TruncatedNormal:
+    """TruncatedNormal(mu, sigma, lo, hi)"""
+
+    def __init__(self, mu, sigma, lo, hi):
+        self.mu, self.sigma, self.lo, self.hi = map(float, (mu, sigma, lo, hi))
+        self._a, self._b = ndtr((self.lo - self.mu) / self.sigma), ndtr((self.hi - self.mu) / self.sigma)
+        self._logz = math.log(self._b - self._a)
+
+    def rand(self, rng):
+        u = self._a + (self._b - self._a) * rng.random()
+        return min(max(self.mu + self.sigma * float(ndtri(u)), self.lo), self.hi)
+
+    def logpdf(self, x):
+        if not self.insupport(x):
+            return -math.inf
+        z = (x - self.mu) / self.sigma
+        return -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma) - self._logz
+
+    def insupport(self, x):
+        return self.lo <= x <= self.hi
+
+
+class LogNormal:
+    def __init__(self, mu=0.0, sigma=1.0):
+        self.mu, self.sigma = float(mu), float(sigma)
+
+    def rand(self, rng):
+        return math.exp(self.mu + self.sigma * rng.standard_normal())
+
+    def logpdf(self, x):
+        if x <= 0:
+            return -math.inf
+        z = (math.log(x) - self.mu) / self.sigma
+        return -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma) - math.log(x)
+
+    def insupport(self, x):
+        return x > 0 and math.isfinite(x)
+
+
+class Uniform:
+    def __init__(self, lo=0.0, hi=1.0):
+        self.lo, self.hi = float(lo), float(hi)
+
+    def rand(self, rng):
+        return self.lo + (self.hi - self.lo) * rng.random()
+
+    def logpdf(self, x):
+        return -math.log(self.hi - self.lo) if self.insupport(x) else -math.inf
+
+    def insupport(self, x):
+        return self.lo <= x <= self.hi
+
+
+class Product:
+    """product_distribution([...]): independent components, theta is a vector."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+
+    def __len__(self):
+        return len(self.parts)
+
+    def rand(self, rng):
+        return np.array([p.rand(rng) for p in self.parts])
+
+    def logpdf(self, theta):
+        return float(sum(p.logpdf(float(t)) for p, t in zip(self.parts, theta)))
+
+    def insupport(self, theta):
+        return all(p.insupport(float(t)) for p, t in zip(self.parts, theta))
+
+
+def product_distribution(parts):
+    return Product(parts)

@@ -1,0 +1,272 @@
+"""Host mirror of src/smc_samplers.jl: SMC, density_tempered, smc2 ("smc²"), smc2_step ("smc²!").
+
+The O(n_theta) outer logic (bisection for the tempering exponent, resample!, the PMMH accept test,
+the random-walk kernel) stays on the host exactly as in the reference; every particle filter the
+reference runs inside `Threads.@threads for m in 1:M` (smc_samplers.jl:112-121,174-180,223-229) or
+serially (:289-295,:325-335) becomes ONE batched call on the GPU (theta axis = workgroups).
+
+theta sharding (multi-GPU): pass `comm=ThetaComm(...)` (distributed.py).  Every rank holds the full
+(small) theta / logZ vectors and draws the same host random numbers from the same seed, so all ranks
+take identical decisions; a rank only *filters* its own contiguous slice of theta, and the slices of
+logZ are exchanged with one all-gather per evaluation (the collective point of SURVEY 8e).
+Results do not depend on the number of ranks: filter m always uses Philox stream id m.
+"""
+import math
+import sys
+
+import numpy as np
+
+from . import _lib
+from .models import params_matrix
+
+
+# ---- filter backends ---------------------------------------------------------------------------
+class HipBackend:
+    """Runs the batched inner filters on one GPU through the C ABI (no CPU fallback)."""
+
+    def __init__(self, device=0, seg=0):
+        self.device, self.seg = device, seg
+        self._handles = {}
+
+    def _handle(self, key, model_id, n_theta, N, seed):
+        k = (key, model_id, n_theta, N)
+        h = self._handles.get(k)
+        if h is None:
+            h = _lib.Handle(model_id, n_theta, N, seg=self.seg, seed=seed, device=self.device)
+            self._handles[k] = h
+        h.reseed(seed)
+        return h
+
+    def log_likelihood(self, models, N, y, seed, streams, key="prop"):
+        mid, raw = params_matrix(models)
+        h = self._handle(key, mid, raw.shape[0], N, seed)
+        h.set_params(raw)
+        h.set_streams(streams)
+        return h.log_likelihood(y), h
+
+    def init(self, models, N, y1, seed, streams, key="main"):
+        mid, raw = params_matrix(models)
+        h = self._handle(key, mid, raw.shape[0], N, seed)
+        h.set_params(raw)
+        h.set_streams(streams)
+        return h.init(y1), h
+
+    def close(self):
+        for h in self._handles.values():
+            h.close()
+        self._handles = {}
+
+
+class SMC:
+    """SMC(N, M, model, prior, chain, ess_threshold, min_ar=-1.0)   smc_samplers.jl:5-59
+    N state particles per filter, M parameter particles.  `model` maps a parameter vector to a
+    StateSpaceModel (the reference's closure smc.model(theta))."""
+
+    def __init__(self, N, M, model, prior, chain, ess_threshold, min_ar=-1.0, seed=1, backend=None, comm=None):
+        self.N, self.M, self.model, self.prior, self.chain = int(N), int(M), model, prior, int(chain)
+        self.rng = np.random.default_rng(seed)
+        self.seed = int(seed)
+        self.theta = np.array([np.atleast_1d(prior.rand(self.rng)) for _ in range(self.M)], dtype=np.float64)
+        self.omega = np.full(self.M, 1.0 / self.M)
+        self.logZ = np.zeros(self.M)
+        self.ess = float(self.M)
+        self.ess_min = self.M * float(ess_threshold)
+        self.acc_threshold, self.acc_ratio = float(min_ar), 0.0
+        self.backend = backend if backend is not None else HipBackend()
+        self.comm = comm
+        self.lo, self.hi = (0, self.M) if comm is None else comm.slice(self.M)
+        self._calls = 0          # evaluation counter -> fresh Philox seed per batched evaluation
+        self.psteps = 0          # executed inner particle-steps (all ranks), SURVEY 8(d)
+        self._main = None        # device handle of the online filters (smc2)
+        self.t = 0
+
+    # -- batched inner filters --------------------------------------------------------------------
+    def _next_seed(self):
+        self._calls += 1
+        return (self.seed << 20) + self._calls
+
+    def _streams(self):
+        return np.arange(self.lo, self.hi, dtype=np.uint32)
+
+    def _gather(self, local):
+        return local if self.comm is None else self.comm.all_gather(local)
+
+    def _filter_all(self, thetas, y, key="prop"):
+        """logZ[m] = log_likelihood(N, y, model(theta[m])) for every m: ONE batched GPU call per rank."""
+        models = [self.model(th) for th in thetas[self.lo:self.hi]]
+        local, h = self.backend.log_likelihood(models, self.N, np.asarray(y, dtype=np.float64), self._next_seed(),
+                                               self._streams(), key=key)
+        self.psteps += self.M * self.N * len(y)
+        return self._gather(np.asarray(local)), h
+
+    def __repr__(self):
+        return "ess     = %.3f\nmean(theta) = %s" % (self.ess, np.array2string(expected_parameters(self)))
+
+
+def _reweight(logw):
+    """reweight == normalize (particles.jl:5-15) on an n_theta-vector: host numpy (O(n_theta))."""
+    logw = np.asarray(logw, dtype=np.float64)
+    m = np.max(logw)
+    if not np.isfinite(m):
+        return -math.inf, np.full(logw.size, 1.0 / logw.size), 0.0
+    w = np.exp(logw - m)
+    s = w.sum()
+    w = w / s
+    return m + math.log(s) - math.log(logw.size), w, 1.0 / float(np.sum(w * w))
+
+
+def expected_parameters(smc):
+    """sum_m theta[m] * omega[m]   (smc_samplers.jl:61-65; omega normalised)"""
+    w = smc.omega / smc.omega.sum()
+    return (smc.theta * w[:, None]).sum(axis=0)
+
+
+def resample_(smc):
+    """resample!(smc)   smc_samplers.jl:74-84 -- value-copy semantics."""
+    w = smc.omega / smc.omega.sum()
+    a = smc.rng.choice(smc.M, size=smc.M, replace=True, p=w)     # iid multinomial, unsorted
+    smc.theta = smc.theta[a].copy()
+    smc.omega = smc.omega[a].copy()
+    smc.logZ = smc.logZ[a].copy()
+    if smc._main is not None:
+        if smc.comm is not None:
+            raise NotImplementedError("online smc2 with theta sharding moves x-clouds between GPUs (SURVEY 8f.2)")
+        smc._main.permute(a.astype(np.int32))
+    return a
+
+
+def random_walk_kernel(theta):
+    """random_walk_kernel(theta::Vector{Vector{Float64}})   smc_samplers.jl:95-101
+    returns f(x, scale, rng) -> draw from MvNormal(x, scale * Sigma)."""
+    d = theta.shape[1]
+    cov = np.atleast_2d(np.cov(theta.T))
+    if np.linalg.norm(cov) < 1e-8:
+        sigma = 1e-2 * np.eye(d)
+    else:
+        sigma = (2.83 ** 2 / d) * cov + 1e-10 * np.eye(d)
+    L = np.linalg.cholesky(sigma)
+    return lambda x, scale, rng: x + math.sqrt(scale) * (L @ rng.standard_normal(d))
+
+
+def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
+    """rejuvenate!(smc, y, xi)   smc_samplers.jl:103-146 -- PMMH moves, `chain` per parameter particle.
+    All M proposals of one chain position are filtered in one batched call."""
+    kernel = random_walk_kernel(smc.theta)
+    scales = 0.5 * np.arange(smc.chain, 0, -1)          # 0.5*reverse(1:chain)
+    accepted = np.zeros(smc.M, dtype=bool)
+    if verbose:
+        out.write("\t[rejuvenating]")
+    for c in range(smc.chain):
+        prop = np.array([kernel(smc.theta[m], scales[c], smc.rng) for m in range(smc.M)])
+        ok = np.array([smc.prior.insupport(p) for p in prop])
+        u = smc.rng.random(smc.M)
+        safe = np.where(ok[:, None], prop, smc.theta)   # out-of-support proposals are never accepted
+        logZ_prop, hprop = smc._filter_all(safe, y)
+        acc = np.zeros(smc.M, dtype=bool)
+        for m in range(smc.M):
+            if not ok[m]:
+                continue
+            lp_prop, lp_cur = smc.prior.logpdf(prop[m]), smc.prior.logpdf(smc.theta[m])
+            acc_ratio = xi * (logZ_prop[m] - smc.logZ[m]) + (lp_prop - lp_cur)
+            if logZ_prop[m] + lp_prop > -math.inf and math.log(u[m]) < acc_ratio:
+                acc[m] = True
+        smc.theta[acc] = prop[acc]
+        smc.logZ[acc] = logZ_prop[acc]
+        if smc._main is not None and acc[smc.lo:smc.hi].any():
+            smc._main.copy_from(hprop, acc[smc.lo:smc.hi])      # x[m], w[m] <- x_prop, w_prop on the device
+        accepted |= acc
+    smc.omega = np.ones(smc.M)
+    smc.acc_ratio = float(accepted.sum()) / smc.M
+    if verbose:
+        out.write("\tacc_rate: %1.5f" % smc.acc_ratio)
+    return smc
+
+
+def density_tempered(smc, y, verbose=True, out=sys.stdout):
+    """density_tempered(smc, y)   smc_samplers.jl:222-281 (Duan & Fulop)."""
+    y = np.asarray(y, dtype=np.float64)
+    smc.logZ, _ = smc._filter_all(smc.theta, y)
+    _, smc.omega, smc.ess = _reweight(smc.logZ)
+    xi = 0.0
+    stages = []
+    while xi < 1.0:
+        resample_flag = True
+        lower, old, upper = xi, xi, 2.0
+        newxi = xi
+        while upper - lower > 1e-6:                       # bisection for the next exponent
+            newxi = (upper + lower) / 2.0
+            _, smc.omega, smc.ess = _reweight((newxi - old) * smc.logZ)
+            if smc.ess == smc.ess_min:
+                break
+            elif smc.ess < smc.ess_min:
+                upper = newxi
+            else:
+                lower = newxi
+        if newxi >= 1.0:                                  # corner solution
+            resample_flag = False
+            newxi = 1.0
+            _, smc.omega, smc.ess = _reweight((newxi - old) * smc.logZ)
+        xi = newxi
+        if verbose:
+            out.write("ξ = %1.5f\tess = %4.3f" % (xi, smc.ess))
+        if resample_flag:
+            resample_(smc)
+            rejuvenate_(smc, y, xi, verbose, out)
+        stages.append((xi, smc.ess, smc.acc_ratio if resample_flag else None))
+        if verbose:
+            out.write("\n")
+    return stages
+
+
+def smc2(smc, y):
+    """smc²(smc, y): initialisation at t = 1   smc_samplers.jl:288-301"""
+    y = np.asarray(y, dtype=np.float64)
+    if smc.comm is not None:
+        raise NotImplementedError("online smc2 with theta sharding moves x-clouds between GPUs (SURVEY 8f.2)")
+    models = [smc.model(th) for th in smc.theta]
+    logmu, smc._main = smc.backend.init(models, smc.N, float(y[0]), smc._next_seed(), smc._streams(), key="main")
+    smc.psteps += smc.M * smc.N
+    smc.logZ = np.asarray(logmu, dtype=np.float64).copy()
+    _, smc.omega, smc.ess = _reweight(smc.logZ)
+    smc.t = 1
+    return smc
+
+
+def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
+    """smc²!(smc, y, t): online step for observation y[t] (1-based t as in the reference, t >= 2)
+    smc_samplers.jl:308-340"""
+    y = np.asarray(y, dtype=np.float64)
+    if verbose:
+        out.write("t = %4d\tess = %4.3f" % (t - 1, smc.ess))
+    if smc.ess < smc.ess_min:
+        resample_(smc)
+        rejuvenate_(smc, y[: t - 1], 1.0, verbose, out)
+        _exchange(smc, y[: t - 1], verbose, out)
+    logw = np.log(smc.omega)
+    smc._main.set_params(params_matrix([smc.model(th) for th in smc.theta])[1])
+    lik, _ = smc._main.step(float(y[t - 1]))
+    smc.psteps += smc.M * smc.N
+    logw = logw + lik
+    smc.logZ = smc.logZ + lik
+    _, smc.omega, smc.ess = _reweight(logw)
+    smc.t = t
+    if verbose:
+        out.write("\n")
+    return smc
+
+
+def _exchange(smc, y, verbose, out):
+    """exchange!(smc, y)   smc_samplers.jl:163-189 (off unless min_ar > acceptance ratio; default -1)."""
+    if smc.acc_ratio < smc.acc_threshold:
+        if smc.N <= 4096:
+            smc.N *= 2
+            if verbose:
+                out.write("\t%d particles added" % smc.N)
+            models = [smc.model(th) for th in smc.theta]
+            new_logZ, h = smc.backend.log_likelihood(models, smc.N, y, smc._next_seed(), smc._streams(), key="main")
+            smc.psteps += smc.M * smc.N * len(y)
+            smc._main = h
+            _, smc.omega, smc.ess = _reweight(np.asarray(new_logZ) - smc.logZ)
+            smc.logZ = np.asarray(new_logZ, dtype=np.float64).copy()
+        else:
+            out.write("\n\t[cannot exceed max state particles]")

@@ -1,0 +1,65 @@
+"""TEST INFRASTRUCTURE: a filter backend for the samplers that runs every inner filter on the CPU
+oracle instead of the GPU.  Same interface as sequential_monte_carlo_amd.smc_samplers.HipBackend, so
+the sampler's host logic can be (a) tested on CPU, (b) sharded over gloo ranks, and (c) compared
+bit for bit with the HIP backend on the GPU box.  Never imported by the product."""
+import numpy as np
+
+from oracle import binding as ob
+from sequential_monte_carlo_amd.models import params_matrix
+
+
+class OracleHandle:
+    def __init__(self, model_id, raws, N, seg, seed, streams):
+        self.model_id, self.N, self.seg = model_id, N, seg
+        self.n_theta = raws.shape[0]
+        self.f = [ob.Filter(model_id, raws[m], N, seg=seg, seed=seed, stream=int(streams[m])) for m in range(self.n_theta)]
+
+    def set_params(self, raws):
+        for m, f in enumerate(self.f):
+            f.set_params(raws[m])
+
+    def init(self, y1):
+        return np.array([f.bootstrap_filter(y1) for f in self.f])
+
+    def step(self, y):
+        r = [f.step(y) for f in self.f]
+        return np.array([a for a, _ in r]), np.array([b for _, b in r])
+
+    def log_likelihood(self, y):
+        return np.array([f.log_likelihood(y) for f in self.f])
+
+    def permute(self, a):
+        # value copy: snapshot the sources first
+        snap = [ob.Filter(self.model_id, [0.5, 1, 1, 1, 0, 1] if self.model_id == 1 else ([0, 0.5, 1] if self.model_id == 2 else [1, 1, 0, 0, 0]),
+                          self.N, seg=self.seg) for _ in self.f]
+        for s, f in zip(snap, self.f):
+            s.copy_state_from(f)
+        for m, f in enumerate(self.f):
+            f.copy_state_from(snap[int(a[m])])
+
+    def copy_from(self, src, mask):
+        for m, f in enumerate(self.f):
+            if mask[m]:
+                f.copy_state_from(src.f[m])
+
+    def state(self):
+        xs = [f.state() for f in self.f]
+        return np.stack([x[0] for x in xs], axis=1), np.stack([x[1] for x in xs]), None
+
+
+class OracleBackend:
+    def __init__(self, seg=0):
+        self.seg = seg
+
+    def log_likelihood(self, models, N, y, seed, streams, key="prop"):
+        mid, raw = params_matrix(models)
+        h = OracleHandle(mid, raw, N, self.seg, seed, streams)
+        return h.log_likelihood(np.asarray(y, dtype=np.float64)), h
+
+    def init(self, models, N, y1, seed, streams, key="main"):
+        mid, raw = params_matrix(models)
+        h = OracleHandle(mid, raw, N, self.seg, seed, streams)
+        return h.init(float(y1)), h
+
+    def close(self):
+        pass

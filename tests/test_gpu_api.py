@@ -1,0 +1,90 @@
+"""GPU tests of the host mirror (particles.py, smc_samplers.py): the reference's API names over the
+HIP library, checked bit for bit against the same host logic running on the oracle backend."""
+import io
+
+import numpy as np
+import pytest
+
+import sequential_monte_carlo_amd as smc
+from oracle_backend import OracleBackend
+from test_samplers_cpu import LG, lg_mod, lg_prior
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_readme_filter_loop(ob):
+    """README.md:33-61: bootstrap_filter, then bootstrap_filter! per observation with host-side
+    quantiles of x; finally log_likelihood gives the same logZ."""
+    m = smc.UnivariateLinearGaussian(**LG)
+    _, y = smc.simulate(m, 40, seed=1998)
+    x, w, logmu = smc.bootstrap_filter(1024, y[0], m, seed=11)
+    f = ob.Filter(ob.LG1D, m.raw(), 1024, seed=11)
+    assert logmu == f.bootstrap_filter(y[0])
+    logZ = logmu
+    xq = [np.quantile(np.asarray(x), [0.25, 0.5, 0.75])]
+    for t in range(1, 40):
+        logmu, w, ess = smc.bootstrap_filter_(x, w, y[t], m)
+        olm, oess = f.step(y[t])
+        assert (logmu, ess) == (olm, oess)
+        xq.append(np.quantile(np.asarray(x), [0.25, 0.5, 0.75]))
+        logZ += logmu
+    ox, ow, _, _ = f.state()
+    assert np.array_equal(bits(np.asarray(x)), bits(ox[0])) and np.array_equal(bits(np.asarray(w)), bits(ow))
+    x2, w2, logZ2 = smc.log_likelihood(1024, y, m, seed=11)
+    assert logZ2 == pytest.approx(logZ, rel=1e-14) and len(x2) == 1024
+    assert np.array_equal(bits(np.asarray(x2)), bits(ox[0]))
+    # filtered medians follow the data's scale
+    assert np.all(np.abs(np.array(xq)[:, 1]) < 5)
+
+
+def test_batched_models_and_ucsv_shapes(ob):
+    ms = [smc.UnivariateLinearGaussian(A=a, B=1.0, Q=0.9, R=0.8) for a in (0.1, 0.5, 0.9)]
+    _, y = smc.simulate(ms[1], 30)
+    x, w, logZ = smc.log_likelihood(512, y, ms, seed=3)
+    assert logZ.shape == (3,) and np.asarray(x).shape == (3, 512) and np.asarray(w).shape == (3, 512)
+    for k, m in enumerate(ms):
+        assert logZ[k] == ob.Filter(ob.LG1D, m.raw(), 512, seed=3, stream=k).log_likelihood(y)
+    u = smc.unobserved_components_stochastic_volatility(x0=3.0, gamma_eps=0.2, gamma_eta=0.2, log_sigma_eps=0.0, log_sigma_eta=0.0)
+    _, yu = smc.simulate(u, 25)
+    xu, wu, zu, lm, es = smc.log_likelihood(1000, yu, u, seed=2, trace=True)
+    assert np.asarray(xu).shape == (1000, 3) and lm.shape == (25,) and zu == pytest.approx(lm.sum(), rel=1e-13)
+    assert zu == ob.Filter(ob.UCSV3D, u.raw(), 1000, seed=2).log_likelihood(yu)
+    lmu, ww, ess = smc.normalize(np.log(np.arange(1, 101.0)))
+    assert lmu == pytest.approx(np.log(50.5), rel=1e-12) and ww.sum() == pytest.approx(1, abs=1e-12)
+    a = smc.resample(ww, 5000, seed=5)
+    assert a.min() >= 0 and a.max() <= 99 and abs(a.mean() - np.sum(np.arange(100) * ww)) < 2.0
+
+
+def _run(backend, online):
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 24, seed=1998)
+    s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, seed=7, backend=backend)
+    buf = io.StringIO()
+    if online:
+        smc.smc2(s, y)
+        for t in range(2, 25):
+            smc.smc2_step(s, y, t, verbose=True, out=buf)
+        x, w, _ = s._main.state()
+        return s, buf.getvalue(), x, w
+    stages = smc.density_tempered(s, y, verbose=True, out=buf)
+    return s, buf.getvalue(), stages, None
+
+
+def test_density_tempered_hip_equals_oracle_backend():
+    sh, th, stg_h, _ = _run(smc.smc_samplers.HipBackend(), online=False)
+    so, to, stg_o, _ = _run(OracleBackend(), online=False)
+    assert th == to and stg_h == stg_o
+    assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+    assert np.array_equal(bits(sh.omega), bits(so.omega)) and sh.psteps == so.psteps
+
+
+def test_smc2_online_hip_equals_oracle_backend():
+    """smc² / smc²! incl. resample!(permute), PMMH accept (copy_from) on the device."""
+    sh, th, xh, wh = _run(smc.smc_samplers.HipBackend(), online=True)
+    so, to, xo, wo = _run(OracleBackend(), online=True)
+    assert th == to and "[rejuvenating]" in th
+    assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+    assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo))
