@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,8 +66,9 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from sequential_monte_carlo_amd import _lib as L
 
@@ -77,14 +80,16 @@ def main():
         raws[:, 0] = raws[:, 1] = rng.uniform(0.05, 0.6, nth)
     else:
         raws = np.tile(raw, (nth, 1))
-    h = L.Handle(model, nth, nx, seg=args.seg, seed=1, device=local_rank if world > 1 else 0)
+    on_gpu = dist is not None and args.dist_backend == "nccl"
+    h = L.Handle(model, nth, nx, seg=args.seg, seed=1, device=local_rank if on_gpu else 0)
     h.set_params(raws)
     h.set_streams(np.arange(nth, dtype=np.uint32) + rank * nth)      # global theta index
 
     def sync_all():
         h.synchronize()
         if dist is not None:
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             dist.barrier()
 
     def one_pass():
@@ -92,8 +97,8 @@ def main():
         if dist is not None:
             # outer reweight (smc_samplers.jl:232): all-gather the logZ scalars over xGMI, then the
             # replicated normalize on every rank (identical results everywhere)
-            mine = torch.from_numpy(logZ).cuda()
-            allz = torch.empty(world * nth, dtype=torch.float64, device="cuda")
+            mine = torch.from_numpy(logZ).cuda() if on_gpu else torch.from_numpy(logZ)
+            allz = torch.empty(world * nth, dtype=torch.float64, device=mine.device)
             dist.all_gather_into_tensor(allz, mine)
             z = allz.cpu().numpy()
             zmax = z.max()
@@ -112,7 +117,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -152,7 +157,7 @@ def main():
         from oracle import binding as ob
         ob.build()
         if nth == 1:
-            Ts = 24
+            Ts = 96
             f = ob.Filter(model, raw, nx, seg=h.seg, seed=1, stream=0)
             c0 = time.perf_counter()
             f.log_likelihood(y[:Ts])
