@@ -114,7 +114,7 @@ static double rne(double v) { return (v + RND_MAGIC) - RND_MAGIC; }
 static double rne_pos(double v) { return v < 0x1p52 ? (v + 0x1p52) - 0x1p52 : v; }
 
 /* exp(x) = p * 2^k with k = rint(x/ln2) (returned as an integral double), p in [0.707,1.415];
- * |x| <= 1e15 */
+ * |x| <= 7e8 */
 static double exp_parts(double x, double* kout) {
     double k = rne(x * INV_LN2);
     double r = fma(-k, LN2_HI, x);
@@ -147,7 +147,7 @@ double orc_exp(double x) {
 }
 
 /* a log-weight takes part in the normalisation iff it is a number of sane magnitude */
-static int lw_alive(double l) { return l == l && fabs(l) <= 1e15; }
+static int lw_alive(double l) { return l == l && fabs(l) <= 7e8; }   /* |k| < 2^30: exponent differences fit an int32 */
 
 /* q = rint(p * 2^(bits + dk)), dk = k_i - kb <= 0 (integral doubles) */
 static uint64_t fix_weight(double p, double dk, int bits) {

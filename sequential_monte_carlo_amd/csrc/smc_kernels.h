@@ -62,25 +62,34 @@ struct FilterView {
 // ---------------------------------------------------------------------------------------------
 // wave / block primitives (wave64)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
-    return (uint64_t)__shfl_up((unsigned long long)v, d, WAVE);
+// DPP (data-parallel primitives) cross-lane moves: no LDS crossbar traffic, 1 VALU per dword.
+// ctrl: row_shr:n = 0x110+n, row_bcast:15 = 0x142 (row_mask 0xa), row_bcast:31 = 0x143 (row_mask 0xc).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int d) {
-    return (uint64_t)__shfl_xor((unsigned long long)v, d, WAVE);
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_u64z(uint64_t v) {   // lanes without a source read 0
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)v), hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const uint64_t o = shfl_up_u64(v, d);
-        if (lane >= d) v += o;
-    }
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int /*lane*/) {
+    v += dpp_u64z<0x111, 0xf>(v);
+    v += dpp_u64z<0x112, 0xf>(v);
+    v += dpp_u64z<0x114, 0xf>(v);
+    v += dpp_u64z<0x118, 0xf>(v);
+    v += dpp_u64z<0x142, 0xa>(v);
+    v += dpp_u64z<0x143, 0xc>(v);
     return v;
 }
-__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) v += shfl_xor_u64(v, d);
-    return v;
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) { return readlane_u64(wave_incl_scan(v, 0), WAVE - 1); }
+
 // 128-bit unsigned accumulator (sum of q^2).  NOTE: do not "optimise" this into 24-bit limb
 // products: hipcc 7.2 folds (q & 0xFFFFFF)^2 accumulations into v_mad_u64_u32 on the UNMASKED
 // register (wrong sums); the parity tests against the oracle caught it.
@@ -99,15 +108,31 @@ __device__ __forceinline__ U128 sq128(uint64_t q) {
     r.lo = q * q;
     return r;
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ U128 dpp_u128z(U128 v) {
+    return U128{dpp_u64z<CTRL, ROW_MASK>(v.lo), dpp_u64z<CTRL, ROW_MASK>(v.hi)};
+}
+// total over the wave, valid in every lane
 __device__ __forceinline__ U128 wave_sum128(U128 v) {
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) {
-        U128 o;
-        o.lo = shfl_xor_u64(v.lo, d);
-        o.hi = shfl_xor_u64(v.hi, d);
-        v = add128(v, o);
-    }
-    return v;
+    v = add128(v, dpp_u128z<0x111, 0xf>(v));
+    v = add128(v, dpp_u128z<0x112, 0xf>(v));
+    v = add128(v, dpp_u128z<0x114, 0xf>(v));
+    v = add128(v, dpp_u128z<0x118, 0xf>(v));
+    v = add128(v, dpp_u128z<0x142, 0xa>(v));
+    v = add128(v, dpp_u128z<0x143, 0xc>(v));
+    return U128{readlane_u64(v.lo, WAVE - 1), readlane_u64(v.hi, WAVE - 1)};
+}
+// max of an int over the wave, valid in every lane
+__device__ __forceinline__ int wave_max_i32(int v) {
+    constexpr uint32_t LOWEST = 0x80000000u;
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    v = mx(v, (int)dpp_u32<0x111, 0xf>(LOWEST, (uint32_t)v));
+    v = mx(v, (int)dpp_u32<0x112, 0xf>(LOWEST, (uint32_t)v));
+    v = mx(v, (int)dpp_u32<0x114, 0xf>(LOWEST, (uint32_t)v));
+    v = mx(v, (int)dpp_u32<0x118, 0xf>(LOWEST, (uint32_t)v));
+    v = mx(v, (int)dpp_u32<0x142, 0xa>(LOWEST, (uint32_t)v));
+    v = mx(v, (int)dpp_u32<0x143, 0xc>(LOWEST, (uint32_t)v));
+    return __builtin_amdgcn_readlane(v, WAVE - 1);
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -128,6 +153,20 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     if (lane == 0) red[wave] = v;
     __syncthreads();
     double r = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = red[w] > r ? red[w] : r;
+    return r;
+}
+
+// the same for an int (segment exponents), DPP reduction inside the wave
+template <int THREADS>
+__device__ __forceinline__ int block_max_i32(int v, int* red) {
+    constexpr int NW = THREADS / WAVE;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    v = wave_max_i32(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    int r = red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) r = red[w] > r ? red[w] : r;
     return r;
@@ -243,8 +282,10 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     // exp(logw) = p 2^k for every particle: independent of the maximum, so it overlaps the reduction
-    double p[NP][2], kk[NP][2];
-    double kloc = -inf();
+    constexpr int DEAD = (int)0x80000000;
+    double p[NP][2];
+    int kk[NP][2];
+    int kloc = DEAD;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
 #pragma unroll
@@ -252,13 +293,13 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
             const double l = lw[k][j];
             const bool alive = lw_alive(l);
             double kq;
-            const double pq = sp_exp_parts(alive ? l : 0.0, kq);
-            p[k][j] = pq;
-            kk[k][j] = alive ? kq : -inf();
+            p[k][j] = sp_exp_parts(alive ? l : 0.0, kq);
+            kk[k][j] = alive ? (int)kq : DEAD;
             kloc = kk[k][j] > kloc ? kk[k][j] : kloc;
         }
     }
-    const double kb = block_max<THREADS>(kloc, (double*)scr);
+    const int kbi = block_max_i32<THREADS>(kloc, (int*)scr);
+    const double kb = kbi == DEAD ? -inf() : (double)kbi;
 
     uint64_t q[NP][2], ps[NP], incl[NP];
     U128 s2{0, 0};   // sum q^2
@@ -266,7 +307,7 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     for (int k = 0; k < NP; ++k) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const uint64_t qq = (kk[k][j] > -inf()) ? fix_weight(p[k][j], kk[k][j] - kb, FIX_BITS) : 0;
+            const uint64_t qq = (kk[k][j] != DEAD) ? fix_weight_i(p[k][j], kk[k][j] - kbi, FIX_BITS) : 0;
             q[k][j] = qq;
             s2 = add128(s2, sq128(qq));
         }
@@ -444,8 +485,14 @@ struct OffsLds {
     uint64_t* S;        // [nseg_p2]
     uint64_t* scr;
 };
+// ancestor segments of C a workgroup stages in LDS (160 KiB per CU: keep >= 2 workgroups resident)
+__host__ __device__ constexpr int nstage_for(int seg) { return seg >= 8192 ? 1 : (seg >= 4096 ? 2 : 3); }
 __host__ __device__ inline size_t offs_lds_bytes(int nseg_p2, int threads, int np) {
     return (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;
+}
+__host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int np, bool multi) {
+    const size_t base = (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;
+    return multi ? base + (size_t)nstage_for(2 * np * threads) * (2 * np * threads) * 8 : base;
 }
 __device__ __forceinline__ OffsLds carve_offs(char* smem, int nseg_p2) {
     OffsLds o;
@@ -503,6 +550,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
     constexpr int NQ = 2 * NP;   // particles per thread
+    constexpr int NSTAGE = nstage_for(SEG);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int sb = blockIdx.x, th = blockIdx.y, tid = threadIdx.x;
     const int nxt = cur ^ 1;
@@ -516,6 +564,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     uint64_t alive;
     uint64_t Sseg[NQ];
     int bseg[NQ];
+    uint64_t* Cst = nullptr;   // staged segments [NSTAGE][SEG] (MULTI)
+    int blo = 0;
     if (MULTI) {
         const OffsLds L = carve_offs(smem, v.nseg_p2);
         scr = L.scr;
@@ -523,24 +573,52 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         if (sb == 0) {   // the counts of step t+1 accumulate into the other buffer: clear it
             for (int b = tid; b < v.nseg; b += THREADS) v.cnt[(t + 1) & 1][(size_t)th * v.nseg + b] = 0;
         }
-        // child j belongs to the first segment b with off[b] > j
+        // the children of this workgroup are consecutive, hence their segments form a range
+        // [b_lo, b_hi] (usually 1-3 segments): find it once (uniform search), then every child
+        // searches only inside it.  child j belongs to the first segment b with off[b] > j.
+        const unsigned int jfirst = (unsigned int)seg0;
+        const int64_t jl = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - 1;
+        const unsigned int jlast = jl > seg0 ? (unsigned int)jl : jfirst;
+        int b_lo = 0, b_hi = 0;
+        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
+            b_lo += (L.off[b_lo + s - 1] <= jfirst) ? s : 0;
+            b_hi += (L.off[b_hi + s - 1] <= jlast) ? s : 0;
+        }
+        b_lo = b_lo < v.nseg ? b_lo : v.nseg - 1;
+        b_hi = b_hi < v.nseg ? b_hi : v.nseg - 1;
+        b_hi = b_hi < b_lo ? b_lo : b_hi;
+        int w0 = 1;
+        while (w0 < b_hi - b_lo + 1) w0 <<= 1;
+        // stage the first NSTAGE segments of the range into LDS (16 B per lane, coalesced)
+        Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
+        {
+            const uint64_t* src = v.C[cur] + (size_t)th * v.npad + (size_t)b_lo * SEG;
+            const int nst = (b_hi - b_lo + 1) < NSTAGE ? (b_hi - b_lo + 1) : NSTAGE;
+            for (int e = tid; e < nst * (SEG / 2); e += THREADS)
+                reinterpret_cast<ulonglong2*>(Cst)[e] = reinterpret_cast<const ulonglong2*>(src)[e];
+        }
+        blo = b_lo;
         int pos[NQ];
         unsigned int jj[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             jj[i] = (unsigned int)(seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1));
-            pos[i] = 0;
+            pos[i] = b_lo;
         }
-        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
+        for (int s = w0 >> 1; s >= 1; s >>= 1) {
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) pos[i] += (L.off[pos[i] + s - 1] <= jj[i]) ? s : 0;
+            for (int i = 0; i < NQ; ++i) {
+                const int c = pos[i] + s;
+                pos[i] = (c <= b_hi && L.off[c - 1] <= jj[i]) ? c : pos[i];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            bseg[i] = pos[i] < v.nseg ? pos[i] : v.nseg - 1;
+            bseg[i] = pos[i];
             Sseg[i] = L.S[bseg[i]];
             if (SMC_ABL(v, 5)) { bseg[i] = sb; Sseg[i] = 1ull << 50; }
         }
+        __syncthreads();   // staged segments visible
     } else {
         const TableLds L = carve(smem, v.nseg_p2);
         scr = L.scr;
@@ -563,18 +641,47 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], Sseg[2 * k + 1], T2[2 * k + 1], lo);
     }
     int pos[NQ];
-    const uint64_t* Cb[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) { pos[i] = 0; Cb[i] = Cprev + (size_t)bseg[i] * SEG; }
+    for (int i = 0; i < NQ; ++i) pos[i] = 0;
     if (SMC_ABL(v, 0)) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) pos[i] = (int)(T2[i] & (SEG - 1));
+    } else if (MULTI) {
+        // branch-free search in the staged copy (LDS); lanes whose segment is not staged keep a
+        // harmless in-range index and redo the search in global memory below
+        bool far = false;
+        int sidx[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int r = bseg[i] - blo;
+            far |= r >= NSTAGE;
+            sidx[i] = (r < NSTAGE ? r : 0) * SEG;
+        }
+#pragma unroll
+        for (int s = SEG >> 1; s >= 1; s >>= 1) {
+            uint64_t val[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) val[i] = Cst[sidx[i] + pos[i] + s - 1];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
+        }
+        if (__builtin_amdgcn_ballot_w64(far)) {   // rare: very uneven weights spread a workgroup over many segments
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (bseg[i] - blo >= NSTAGE) {
+                    const uint64_t* Cb = Cprev + (size_t)bseg[i] * SEG;
+                    int pp = 0;
+                    for (int s = SEG >> 1; s >= 1; s >>= 1) pp += (Cb[pp + s - 1] <= T2[i]) ? s : 0;
+                    pos[i] = pp;
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int s = SEG >> 1; s >= 1; s >>= 1) {
             uint64_t val[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) val[i] = Cb[i][pos[i] + s - 1];
+            for (int i = 0; i < NQ; ++i) val[i] = Cprev[pos[i] + s - 1];
 #pragma unroll
             for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
         }

@@ -16,7 +16,16 @@ static hipError_t init_t(const FilterView& v, int nxt, double y, hipStream_t s) 
 }
 template <int THREADS, int NP>
 static hipError_t step_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
-    const size_t lds = table_lds_bytes(v.nseg_p2, THREADS, NP);
+    const size_t lds = step_lds_bytes(v.nseg_p2, THREADS, NP, v.nseg > 1);
+    if (lds > 64 * 1024) {
+        static bool raised = false;   // per instantiation
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
     if (v.nseg > 1)
         hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, true>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
                            emit_prev, y);

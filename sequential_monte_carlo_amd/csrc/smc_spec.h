@@ -85,7 +85,7 @@ SMC_HD u32x4 draw(uint64_t seed, uint32_t pair, uint32_t stream, uint32_t t, uin
 }
 
 // ---- exp / log / sincos ----------------------------------------------------------------
-// exp(x) = p * 2^k, k = rint(x / ln2) returned as an integral double, p in [0.707, 1.415]; |x| <= 1e15
+// exp(x) = p * 2^k, k = rint(x / ln2) returned as an integral double, p in [0.707, 1.415]; |x| <= 7e8
 SMC_HD double sp_exp_parts(double x, double& kout) {
     const double k = rne(x * INV_LN2);
     double r = fma(-k, LN2_HI, x);
@@ -118,12 +118,18 @@ SMC_HD double sp_exp(double x) {
 }
 
 // a log-weight takes part in the normalisation iff it is a number of sane magnitude
-SMC_HD bool lw_alive(double l) { return l == l && (l < 0.0 ? -l : l) <= 1e15; }
+SMC_HD bool lw_alive(double l) { return l == l && (l < 0.0 ? -l : l) <= 7e8; }   // |k| < 2^30: differences fit int32
 
 // q = rint(p * 2^(bits + dk)),  dk = k_i - kb <= 0 (integral doubles)
 SMC_HD uint64_t fix_weight(double p, double dk, int bits) {
     if (dk < -(double)(bits + 2)) return 0;
     return (uint64_t)rne_pos(p * pow2i(bits + (int)dk));
+}
+// the same value for an integer exponent difference, with the rounding and the conversion done by
+// ONE addition: v < 2^50, so v + 2^52 holds rint(v) in its low mantissa bits
+SMC_HD uint64_t fix_weight_i(double p, int dk, int bits) {
+    if (dk < -(bits + 2)) return 0;
+    return d2bits(p * pow2i(bits + dk) + 0x1p52) & 0x000fffffffffffffULL;
 }
 
 SMC_HD double sp_log(double x) {
