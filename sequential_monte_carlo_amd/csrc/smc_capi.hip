@@ -188,6 +188,10 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     v.SH = table_shift_extra(v.npad);
 #ifdef SMC_ABLATE
     v.abl = h_abl_tmp;
+    if (getenv("SMC_DBG")) {
+        if (hipMalloc((void**)&v.dbg, (size_t)v.ntheta * v.nseg * 64) != hipSuccess) v.dbg = nullptr;
+        else (void)hipMemset(v.dbg, 0, (size_t)v.ntheta * v.nseg * 64);
+    }
 #endif
     h->resident_ok = (v.nseg == 1) && !(flags & SMC_FLAG_NO_RESIDENT);
 
@@ -244,6 +248,28 @@ extern "C" int smc_destroy(smc_handle h) {
     if (!h) return SMC_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+#ifdef SMC_ABLATE
+    if (h->v.dbg) {   // phase profile of the LAST k_step launch: mean over workgroups, in microseconds
+        const size_t nwg = (size_t)h->v.ntheta * h->v.nseg;
+        std::vector<unsigned long long> st(nwg * 8);
+        (void)hipMemcpy(st.data(), h->v.dbg, nwg * 64, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t7 = 0;
+        double ph[8] = {0};
+        for (size_t w = 0; w < nwg; ++w) {
+            if (st[w * 8] < t0) t0 = st[w * 8];
+            if (st[w * 8 + 7] > t7) t7 = st[w * 8 + 7];
+            for (int k = 1; k < 8; ++k) ph[k] += (double)(st[w * 8 + k] - st[w * 8 + k - 1]) * 0.01;
+        }
+        double start_spread = 0, life = 0;
+        for (size_t w = 0; w < nwg; ++w) { start_spread += (double)(st[w * 8] - t0) * 0.01; life += (double)(st[w * 8 + 7] - st[w * 8]) * 0.01; }
+        fprintf(stderr, "[dbg] k_step span %.2f us; mean start offset %.2f us; mean WG life %.2f us; phases(us):", (double)(t7 - t0) * 0.01,
+                start_spread / nwg, life / nwg);
+        const char* nm[8] = {"", "offsets", "range+stage-issue+lookup", "normals", "T2+stage-write+barrier", "search", "gather+model+store", "epilogue"};
+        for (int k = 1; k < 8; ++k) fprintf(stderr, " %s=%.2f", nm[k], ph[k] / nwg);
+        fprintf(stderr, "\n");
+        (void)hipFree(h->v.dbg);
+    }
+#endif
     FilterView& v = h->v;
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]); (void)hipFree(v.cnt[b]);

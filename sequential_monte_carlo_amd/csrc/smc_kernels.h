@@ -51,12 +51,20 @@ struct FilterView {
     double* trace_ess;       // [T][ntheta] or nullptr
     const double* y;         // [T] on device (log_likelihood) or nullptr
     int abl;                 // ablation mask: always 0 in the product (profiling builds only, -DSMC_ABLATE)
+    unsigned long long* dbg; // phase stamps [workgroup][8] (profiling builds only), else nullptr
 };
 
 #ifdef SMC_ABLATE
 #define SMC_ABL(v, bit) (((v).abl >> (bit)) & 1)
+// phase stamp k of this workgroup (100 MHz constant clock); diagnostic build only
+#define SMC_STAMP(v, k)                                                                                   \
+    do {                                                                                                  \
+        if ((v).dbg && threadIdx.x == 0)                                                                  \
+            (v).dbg[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define SMC_ABL(v, bit) 0
+#define SMC_STAMP(v, k) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -371,6 +379,15 @@ __device__ __forceinline__ void segment_epilogue(const FilterView& v, int nxt, i
 
 __device__ __forceinline__ double nan_mask() { return bits2d(0x7ff8000000000000ULL); }
 
+// XCD-aware block -> segment map (speed only, never correctness): workgroups are dealt round-robin
+// over the 8 XCDs, so blocks with equal blockIdx.x % 8 share an L2.  Give each XCD a CONTIGUOUS
+// range of segments: the workgroup that wrote segment b at step t-1 and the workgroups that read
+// segments b-1..b+1 at step t (children are segment-sorted) then sit on the same XCD, and the
+// staging loads / gathers hit that XCD's 4 MiB L2 instead of going out to the Infinity Cache.
+__device__ __forceinline__ int logical_segment(int bid, int nseg) {
+    return (nseg & 7) ? bid : (bid & 7) * (nseg >> 3) + (bid >> 3);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_init : bootstrap_filter  (particles.jl:87-105)    grid (nseg, ntheta)
 // ---------------------------------------------------------------------------------------------
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
     constexpr int D = model_dim<MODEL>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* scr = (uint64_t*)smem;
-    const int sb = blockIdx.x, th = blockIdx.y, tid = threadIdx.x;
+    const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = threadIdx.x;
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
     const int64_t seg0 = (int64_t)sb * v.seg;
@@ -438,12 +455,20 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
     const TableLds L = carve(smem, v.nseg_p2);
     unsigned int* hist = (unsigned int*)(L.scr + scr_words(THREADS, 1));   // [nseg_p2]
     for (int b = tid; b < v.nseg_p2; b += THREADS) hist[b] = 0;
-    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u);
-    if (Dtot == 0) return;   // collapsed filter: counts stay 0, k_step falls back to identity
     const uint32_t stream = v.stream[th];
     const int64_t npairs = (v.n + 1) >> 1;
     const int64_t per = (npairs + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < npairs) ? p0 + per : npairs;
+    // first trip's Philox draws are issued before the table exists (they only need the indices)
+    uint64_t r4[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const u32x4 rw = draw(v.seed, (uint32_t)(p0 + tid + u * THREADS), stream, t, SLOT_COUNT);
+        r4[2 * u] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
+        r4[2 * u + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
+    }
+    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u);
+    if (Dtot == 0) return;   // collapsed filter: counts stay 0, k_step falls back to identity
     for (int64_t pb = p0; pb < p1; pb += 2 * THREADS) {
         // two pairs (four draws) per thread per trip: independent LDS searches in flight
         uint64_t T1[4];
@@ -451,10 +476,14 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int64_t p = pb + tid + u * THREADS;
-            const u32x4 rw = draw(v.seed, (uint32_t)p, stream, t, SLOT_COUNT);
+            if (pb != p0) {
+                const u32x4 rw = draw(v.seed, (uint32_t)p, stream, t, SLOT_COUNT);
+                r4[2 * u] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
+                r4[2 * u + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
+            }
             uint64_t lo;
-            mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], Dtot, T1[2 * u], lo);
-            mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], Dtot, T1[2 * u + 1], lo);
+            mul64wide(r4[2 * u], Dtot, T1[2 * u], lo);
+            mul64wide(r4[2 * u + 1], Dtot, T1[2 * u + 1], lo);
             ok[2 * u] = p < p1 && 2 * p < v.n;
             ok[2 * u + 1] = p < p1 && 2 * p + 1 < v.n;
         }
@@ -501,15 +530,20 @@ __device__ __forceinline__ OffsLds carve_offs(char* smem, int nseg_p2) {
     o.scr = (uint64_t*)(smem + (size_t)nseg_p2 * 16);
     return o;
 }
+// `pre`: this thread's (count, S) entry was loaded early by the caller (only when nseg_p2 <= THREADS).
 template <int THREADS>
-__device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, int cur, int th, uint32_t t, const OffsLds& L) {
+__device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, int cur, int th, uint32_t t, const OffsLds& L,
+                                                         bool pre, unsigned int pre_cnt, uint64_t pre_S) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const unsigned int* cn = v.cnt[t & 1] + (size_t)th * v.nseg;
     const uint64_t* sS = v.segS[cur] + (size_t)th * v.nseg;
     const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1;
     uint64_t run = 0;
-    if (tid * E < v.nseg_p2) {
+    if (pre) {
+        run = pre_cnt;
+        if (tid < v.nseg_p2) { L.off[tid] = pre_cnt; L.S[tid] = pre_S; }
+    } else if (tid * E < v.nseg_p2) {
         for (int e = 0; e < E; ++e) {
             const int b = tid * E + e;
             const bool in = b < v.nseg;
@@ -552,13 +586,36 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     constexpr int NQ = 2 * NP;   // particles per thread
     constexpr int NSTAGE = nstage_for(SEG);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int sb = blockIdx.x, th = blockIdx.y, tid = threadIdx.x;
+    const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = threadIdx.x;
     const int nxt = cur ^ 1;
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
     const double y = v.y ? v.y[t] : yval;
     const int64_t seg0 = (int64_t)sb * SEG;
+    const uint64_t* Cprev = v.C[cur] + (size_t)th * v.npad;
+    const double* xprev = v.x[cur];
     uint64_t* scr;
+    SMC_STAMP(v, 0);
+
+    // Issue-early / use-late: every load whose address is known is issued BEFORE the random-number
+    // work (Philox + Box-Muller is most of this kernel's VALU), which then runs under the latency.
+    // (1) this thread's entry of the children counts and segment sums (MULTI)
+    const bool pre = MULTI && v.nseg_p2 <= THREADS;
+    unsigned int pre_cnt = 0;
+    uint64_t pre_S = 0;
+    if (pre && tid < v.nseg) {
+        pre_cnt = v.cnt[t & 1][(size_t)th * v.nseg + tid];
+        pre_S = v.segS[cur][(size_t)th * v.nseg + tid];
+    }
+    // (2) the 64-bit pick numbers of this thread's children
+    uint64_t rr[NQ];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
+        const u32x4 rw = SMC_ABL(v, 3) ? u32x4{{pg * 2654435761u, pg ^ t, pg * 40503u, ~pg}} : draw(v.seed, pg, stream, t, SLOT_RESAMPLE);
+        rr[2 * k] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
+        rr[2 * k + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
+    }
 
     // alive = some weight is positive; otherwise the filter collapsed and ancestors are the identity
     uint64_t alive;
@@ -566,10 +623,12 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     int bseg[NQ];
     uint64_t* Cst = nullptr;   // staged segments [NSTAGE][SEG] (MULTI)
     int blo = 0;
+    ulonglong2 stg[NSTAGE][NP];   // staging registers: NP 16-byte pieces per thread per staged segment
     if (MULTI) {
         const OffsLds L = carve_offs(smem, v.nseg_p2);
         scr = L.scr;
-        alive = SMC_ABL(v, 5) ? 1u : offsets_prologue<THREADS>(v, cur, th, t, L);
+        alive = SMC_ABL(v, 5) ? 1u : offsets_prologue<THREADS>(v, cur, th, t, L, pre, pre_cnt, pre_S);
+        SMC_STAMP(v, 1);
         if (sb == 0) {   // the counts of step t+1 accumulate into the other buffer: clear it
             for (int b = tid; b < v.nseg; b += THREADS) v.cnt[(t + 1) & 1][(size_t)th * v.nseg + b] = 0;
         }
@@ -589,13 +648,15 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         b_hi = b_hi < b_lo ? b_lo : b_hi;
         int w0 = 1;
         while (w0 < b_hi - b_lo + 1) w0 <<= 1;
-        // stage the first NSTAGE segments of the range into LDS (16 B per lane, coalesced)
+        // (3) issue the loads of the first NSTAGE segments of the range (16 B per lane, coalesced);
+        //     they land in LDS after the normals have been computed
         Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
-        {
-            const uint64_t* src = v.C[cur] + (size_t)th * v.npad + (size_t)b_lo * SEG;
-            const int nst = (b_hi - b_lo + 1) < NSTAGE ? (b_hi - b_lo + 1) : NSTAGE;
-            for (int e = tid; e < nst * (SEG / 2); e += THREADS)
-                reinterpret_cast<ulonglong2*>(Cst)[e] = reinterpret_cast<const ulonglong2*>(src)[e];
+#pragma unroll
+        for (int sg = 0; sg < NSTAGE; ++sg) {   // unconditional (clamped) loads keep stg[] in registers
+            const int bs = (b_lo + sg <= b_hi) ? b_lo + sg : b_lo;   // unneeded slots re-read b_lo (cache hit)
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)bs * SEG);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
         }
         blo = b_lo;
         int pos[NQ];
@@ -618,7 +679,6 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             Sseg[i] = L.S[bseg[i]];
             if (SMC_ABL(v, 5)) { bseg[i] = sb; Sseg[i] = 1ull << 50; }
         }
-        __syncthreads();   // staged segments visible
     } else {
         const TableLds L = carve(smem, v.nseg_p2);
         scr = L.scr;
@@ -627,19 +687,38 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 #pragma unroll
         for (int i = 0; i < NQ; ++i) { bseg[i] = 0; Sseg[i] = alive; }
     }
-    const uint64_t* Cprev = v.C[cur] + (size_t)th * v.npad;
-    const double* xprev = v.x[cur];
 
-    // ---- a = resample(weights), level 2: iid pick inside the child's segment -------------------
-    uint64_t T2[NQ];
+    SMC_STAMP(v, 2);
+    // ---- the state normals of this thread's children (under the staging loads) ----------------
+    double z[NP][D][2];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
-        const u32x4 rw = SMC_ABL(v, 3) ? u32x4{{pg * 2654435761u, pg ^ t, pg * 40503u, ~pg}} : draw(v.seed, pg, stream, t, SLOT_RESAMPLE);
-        uint64_t lo;
-        mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], Sseg[2 * k], T2[2 * k], lo);
-        mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], Sseg[2 * k + 1], T2[2 * k + 1], lo);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            if (SMC_ABL(v, 2)) { z[k][c][0] = 1e-3 * (double)(pg & 1023); z[k][c][1] = -z[k][c][0]; }
+            else if (SMC_ABL(v, 6)) { const u32x4 w4 = draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c); z[k][c][0] = 1e-9 * (double)w4.v[0]; z[k][c][1] = 1e-9 * (double)w4.v[2]; }
+            else box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[k][c][0], z[k][c][1]);
+        }
     }
+
+    SMC_STAMP(v, 3);
+    // ---- a = resample(weights), level 2: iid pick inside the child's segment -------------------
+    uint64_t T2[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        uint64_t lo;
+        mul64wide(rr[i], Sseg[i], T2[i], lo);
+    }
+    if (MULTI) {
+#pragma unroll
+        for (int sg = 0; sg < NSTAGE; ++sg)
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                reinterpret_cast<ulonglong2*>(Cst)[sg * (SEG / 2) + tid + k * THREADS] = stg[sg][k];
+        __syncthreads();   // staged segments visible
+    }
+    SMC_STAMP(v, 4);
     int pos[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) pos[i] = 0;
@@ -686,6 +765,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
         }
     }
+    SMC_STAMP(v, 5);
     int64_t anc[NQ];
     double xp[NQ][D];
 #pragma unroll
@@ -704,19 +784,12 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int64_t i0 = seg0 + 2 * (tid + k * THREADS);
-        const uint32_t pg = (uint32_t)(i0 >> 1);
-        double z[D][2], xn[2][D];
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            if (SMC_ABL(v, 2)) { z[c][0] = 1e-3 * (double)(pg & 1023); z[c][1] = -z[c][0]; }
-            else if (SMC_ABL(v, 6)) { const u32x4 w4 = draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c); z[c][0] = 1e-9 * (double)w4.v[0]; z[c][1] = 1e-9 * (double)w4.v[2]; }
-            else box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[c][0], z[c][1]);
-        }
+        double xn[2][D];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             double zz[D];
 #pragma unroll
-            for (int c = 0; c < D; ++c) zz[c] = z[c][j];
+            for (int c = 0; c < D; ++c) zz[c] = z[k][c][j];
             model_transition<MODEL>(prm, xp[2 * k + j], zz, xn[j]);
             const bool valid = (i0 + j) < v.n;
             lw[k][j] = valid ? model_logobs<MODEL>(prm, xn[j], y) : nan_mask();
@@ -735,6 +808,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             *reinterpret_cast<int2*>(v.anc + (size_t)th * v.npad + i0) = o;
         }
     }
+    SMC_STAMP(v, 6);
     if (SMC_ABL(v, 4)) {   // keep lw alive, skip the normalisation
         double acc = 0;
 #pragma unroll
@@ -743,6 +817,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         return;
     }
     segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
+    SMC_STAMP(v, 7);
 }
 
 // ---------------------------------------------------------------------------------------------
