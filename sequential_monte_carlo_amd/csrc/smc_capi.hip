@@ -44,6 +44,7 @@ struct smc_filter_s {
     int64_t trcap = 0;
     double* d_wdense = nullptr;
     StepRec* d_recs = nullptr;
+    unsigned long long* dbg_count = nullptr;   // diagnostic builds only
     int64_t reccap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -126,6 +127,14 @@ hipError_t launch_count(const FilterView& v, int cur, uint32_t t, int emit_prev,
 }  // namespace smc
 static hipError_t do_count(smc_filter_s* h, uint32_t t, int emit_prev) {
     if (h->v.nseg <= 1) return hipSuccess;   // single segment: every child picks in segment 0
+#ifdef SMC_ABLATE
+    if (getenv("SMC_DBG_COUNT")) {
+        if (!h->dbg_count && hipMalloc((void**)&h->dbg_count, 1024 * 64) == hipSuccess) (void)hipMemset(h->dbg_count, 0, 1024 * 64);
+        FilterView vv = h->v;
+        vv.dbg = h->dbg_count;
+        return launch_count(vv, h->cur, t, emit_prev, h->stream);
+    }
+#endif
     return launch_count(h->v, h->cur, t, emit_prev, h->stream);
 }
 static hipError_t do_resident(smc_filter_s* h, int T) {
@@ -188,7 +197,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     v.SH = table_shift_extra(v.npad);
 #ifdef SMC_ABLATE
     v.abl = h_abl_tmp;
-    if (getenv("SMC_DBG")) {
+    if (getenv("SMC_DBG") && !getenv("SMC_DBG_COUNT")) {
         if (hipMalloc((void**)&v.dbg, (size_t)v.ntheta * v.nseg * 64) != hipSuccess) v.dbg = nullptr;
         else (void)hipMemset(v.dbg, 0, (size_t)v.ntheta * v.nseg * 64);
     }
@@ -249,6 +258,22 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
 #ifdef SMC_ABLATE
+    if (h->dbg_count) {
+        const size_t nwg = 1024;
+        std::vector<unsigned long long> st(nwg * 8);
+        (void)hipMemcpy(st.data(), h->dbg_count, nwg * 64, hipMemcpyDeviceToHost);
+        size_t used = 0; double ph[8] = {0}; unsigned long long t0 = ~0ull, t5 = 0;
+        for (size_t w = 0; w < nwg; ++w) {
+            if (!st[w * 8 + 5]) continue;
+            ++used;
+            if (st[w * 8] < t0) t0 = st[w * 8];
+            if (st[w * 8 + 5] > t5) t5 = st[w * 8 + 5];
+            for (int k = 1; k < 6; ++k) ph[k] += (double)(st[w * 8 + k] - st[w * 8 + k - 1]) * 0.01;
+        }
+        fprintf(stderr, "[dbg] k_count %zu WGs span %.2f us; phases(us): philox=%.2f table=%.2f draws+search+atomics=%.2f barrier=%.2f flush=%.2f\n",
+                used, (double)(t5 - t0) * 0.01, ph[1] / used, ph[2] / used, ph[3] / used, ph[4] / used, ph[5] / used);
+        (void)hipFree(h->dbg_count);
+    }
     if (h->v.dbg) {   // phase profile of the LAST k_step launch: mean over workgroups, in microseconds
         const size_t nwg = (size_t)h->v.ntheta * h->v.nseg;
         std::vector<unsigned long long> st(nwg * 8);

@@ -455,6 +455,7 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
     const TableLds L = carve(smem, v.nseg_p2);
     unsigned int* hist = (unsigned int*)(L.scr + scr_words(THREADS, 1));   // [nseg_p2]
     for (int b = tid; b < v.nseg_p2; b += THREADS) hist[b] = 0;
+    SMC_STAMP(v, 0);
     const uint32_t stream = v.stream[th];
     const int64_t npairs = (v.n + 1) >> 1;
     const int64_t per = (npairs + gridDim.x - 1) / gridDim.x;
@@ -467,7 +468,9 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
         r4[2 * u] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
         r4[2 * u + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
     }
+    SMC_STAMP(v, 1);
     const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u);
+    SMC_STAMP(v, 2);
     if (Dtot == 0) return;   // collapsed filter: counts stay 0, k_step falls back to identity
     for (int64_t pb = p0; pb < p1; pb += 2 * THREADS) {
         // two pairs (four draws) per thread per trip: independent LDS searches in flight
@@ -496,12 +499,15 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
         for (int i = 0; i < 4; ++i)
             if (ok[i]) atomicAdd(&hist[pos[i]], 1u);
     }
+    SMC_STAMP(v, 3);
     __syncthreads();
+    SMC_STAMP(v, 4);
     unsigned int* out = v.cnt[t & 1] + (size_t)th * v.nseg;
     for (int b = tid; b < v.nseg; b += THREADS) {
         const unsigned int c = hist[b];
         if (c) atomicAdd(&out[b], c);
     }
+    SMC_STAMP(v, 5);
 }
 __host__ __device__ inline size_t count_lds_bytes(int nseg_p2, int threads) {
     return table_lds_bytes(nseg_p2, threads, 1) + (size_t)nseg_p2 * 4;

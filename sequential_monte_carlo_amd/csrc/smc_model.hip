@@ -1,6 +1,7 @@
 // smc_model.hip -- instantiates the kernels of ONE model family (-DSMC_MODEL=1|2|3) for every
 // workgroup geometry.  Three objects are built in parallel and linked into libsmchip.so.
 #include "smc_launch.h"
+#include <cstdlib>
 
 #ifndef SMC_MODEL
 #error "compile with -DSMC_MODEL=<model id>"
@@ -76,11 +77,13 @@ static hipError_t resident_t(const FilterView& v, int T, StepRec* recs, hipStrea
 
 template <>
 hipError_t launch_resident<SMC_MODEL>(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
+    const char* e = getenv("SMC_RES_NP");   // tuning knob
+    const int np = e ? atoi(e) : 0;
     switch (v.seg) {
     case 256: return resident_t<128, 1>(v, T, recs, s);
     case 512: return resident_t<256, 1>(v, T, recs, s);
-    case 1024: return resident_t<256, 2>(v, T, recs, s);
-    case 2048: return resident_t<512, 2>(v, T, recs, s);
+    case 1024: return np == 1 ? resident_t<512, 1>(v, T, recs, s) : np == 4 ? resident_t<128, 4>(v, T, recs, s) : resident_t<256, 2>(v, T, recs, s);
+    case 2048: return np == 1 ? resident_t<1024, 1>(v, T, recs, s) : np == 4 ? resident_t<256, 4>(v, T, recs, s) : resident_t<512, 2>(v, T, recs, s);
     case 4096: return resident_t<1024, 2>(v, T, recs, s);
     case 8192:
         if constexpr (model_dim<SMC_MODEL>::value == 1) return resident_t<1024, 4>(v, T, recs, s);

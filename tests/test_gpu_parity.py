@@ -318,3 +318,63 @@ def test_full_size_c5_ucsv_shape(L):
     near = z[np.abs(raws[:, 0] - 0.2) < 0.05].mean()
     assert near > z[raws[:, 0] > 0.5].mean() and near > z[raws[:, 0] < 0.08].mean()
     h.close()
+
+
+def test_uneven_weights_far_segments(L, ob):
+    """Very informative observations (tiny R) make the weights wildly uneven: most segments get a
+    handful of children, a few get hundreds, so one workgroup's children span more segments than it
+    stages in LDS and the global-memory fallback of the segment search runs.  Still bit-exact."""
+    for R, n, seg in ((1e-4, 5000, 256), (1e-6, 20000, 256), (1e-3, 40000, 1024), (1e-5, 70000, 2048)):
+        raw = [0.9, 1.0, 1.0, R, 0.0, 4.0]
+        _, y = ob.simulate(1, [0.9, 1.0, 1.0, 0.5, 0.0, 4.0], 12, 7)
+        h = L.Handle(1, 2, n, seg=seg, seed=13, flags=L.FLAG_ANCESTORS)
+        h.set_params(np.tile(raw, (2, 1)))
+        logZ, lm, es = h.log_likelihood(y, trace=True)
+        x, w, a = h.state()
+        assert es.min() < 0.02 * n                      # the weights really are degenerate
+        for th in range(2):
+            f = ob.Filter(1, raw, n, seg=seg, seed=13, stream=th)
+            z, olm, oes = f.log_likelihood(y, trace=True)
+            ox, ow, oa, _ = f.state()
+            assert bits([logZ[th]])[0] == bits([z])[0] and same(lm[:, th], olm) and same(es[:, th], oes)
+            assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa)
+            segs = a[th] // seg
+            assert np.all(np.diff(segs) >= 0)           # children come out sorted by ancestor segment
+        h.close()
+
+
+def test_step_api_multi_segment_with_permute_and_copy(L, ob):
+    """smc_step on multi-segment filters interleaved with smc_permute / smc_copy_from."""
+    _, y = ob.simulate(1, LG, 10, 1998)
+    n, seg, nth = 3000, 1024, 3
+    h = L.Handle(1, nth, n, seg=seg, seed=21)
+    g = L.Handle(1, nth, n, seg=seg, seed=22)
+    for hh in (h, g):
+        hh.set_params(np.tile(LG, (nth, 1)))
+        hh.init(y[0])
+        for t in range(1, 4):
+            hh.step(y[t])
+    xg, wg, _ = g.state(want_anc=False)
+    zg, _ = g.logZ()
+    h.copy_from(g, [1, 0, 1])
+    x, w, _ = h.state(want_anc=False)
+    z, _ = h.logZ()
+    assert same(x[:, 0], xg[:, 0]) and same(x[:, 2], xg[:, 2]) and not same(x[:, 1], xg[:, 1])
+    assert same(w[0], wg[0]) and z[0] == zg[0] and z[2] == zg[2]
+    h.permute(np.array([2, 2, 1], dtype=np.int32))
+    x2, w2, _ = h.state(want_anc=False)
+    assert same(x2[:, 0], x[:, 2]) and same(x2[:, 1], x[:, 2]) and same(x2[:, 2], x[:, 1])
+    lm, ess = h.step(y[4])
+    assert np.all(np.isfinite(lm)) and lm[0] != lm[1]
+    _, w3, _ = h.state(want_anc=False)
+    assert np.allclose(w3.sum(axis=1), 1.0, atol=1e-12)
+    h.close(); g.close()
+
+
+def test_time_step_kernel_runs(L):
+    _, y = L.simulate(1, LG, 40, 1998)
+    h = L.Handle(1, 1, 1 << 16, seed=1)
+    h.set_params(LG)
+    avg, mn = h.time_step_kernel(y, nsample=8)
+    assert 0 < mn <= avg < 5.0
+    h.close()
