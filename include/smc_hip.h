@@ -98,6 +98,18 @@ int smc_normalize(const double* logw, int64_t n, double* w, double* logmu, doubl
 int smc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t seed, uint32_t stream, uint32_t t, int32_t* a,
                  int device);
 
+/* ---- SURVEY 8(f) "next" rows --------------------------------------------------------------------*/
+/* log_likelihood(y, model::LinearModel) -> (x_T, Sigma_T, logZ): exact scalar Kalman filter,
+ * src/kalman_filter.jl:29-70, for n_theta parameter rows at once (the inner "filter" of the IBIS
+ * sampler src/ibis.jl:134-189, and a self-check of linear-Gaussian particle runs).
+ * raw [n_theta][6] = (A,B,Q,R,x0,sigma0); out [n_theta][3]. predict_first != 0 is the literal
+ * reference loop; 0 starts at x_1 ~ N(x0, sigma0) like bootstrap_filter. */
+int smc_kalman_log_likelihood(const double* raw, int64_t n_theta, const double* y, int64_t T, int predict_first,
+                              double* out /*[n_theta][3]*/, int device);
+/* filtered mean and variance of every state coordinate under the current weights, on the device
+ * (README.md:41,51 summaries; src/plotting_utils.jl:116-124 estimated_trend). mean, var: [d][n_theta]. */
+int smc_get_moments(smc_handle h, double* mean, double* var);
+
 /* ---- host-side helpers (no GPU needed) ---------------------------------------------------------*/
 /* simulate(rng, model, T) -> (x, y)                         src/state_space_models.jl:11-26 */
 int smc_simulate(int model_id, const double* raw, int64_t T, uint64_t seed, double* x /*[d][T]*/, double* y /*[T]*/);

@@ -64,6 +64,10 @@ def lib():
         L.orc_filter_ess.argtypes = [C.c_void_p]
         L.orc_filter_seg.argtypes = [C.c_void_p]
         L.orc_filter_get_weights_raw.argtypes = [C.c_void_p, _u64p, _dp, _u64p, _u64p, _u64p]
+        L.orc_kalman_log_likelihood.argtypes = [_dp, _dp, C.c_int64, C.c_int, _dp]
+        L.orc_kalman_log_likelihood.restype = None
+        L.orc_filter_moments.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_filter_moments.restype = None
         L.orc_log_likelihood_batch.argtypes = [C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_uint64,
                                                C.c_uint32, _dp, C.c_int, _dp]
         _lib = L
@@ -195,6 +199,11 @@ class Filter:
         lib().orc_filter_get_state(self._h, _d(x), _d(w), a.ctypes.data_as(_i64p), _d(logw))
         return x, w, a, logw
 
+    def moments(self):
+        m, v = np.zeros(self.d), np.zeros(self.d)
+        lib().orc_filter_moments(self._h, _d(m), _d(v))
+        return m, v
+
     def weights_raw(self):
         ns = self.nseg
         Cc = np.zeros(ns * self.seg, dtype=np.uint64)
@@ -215,3 +224,12 @@ def log_likelihood_batch(model, raw, n, y, seg=0, seed=1, stream0=0):
     rc = lib().orc_log_likelihood_batch(model, _d(raw), nth, n, seg, seed, stream0, _d(y), y.size, _d(out))
     assert rc == 0
     return out
+
+
+def kalman_log_likelihood(raw, y, predict_first=False):
+    """(x_T, Sigma_T, logZ) of the scalar Kalman filter, src/kalman_filter.jl:29-70."""
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros(3)
+    lib().orc_kalman_log_likelihood(_d(raw), _d(y), y.size, int(predict_first), _d(out))
+    return out[0], out[1], out[2]

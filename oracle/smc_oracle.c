@@ -67,6 +67,7 @@ typedef unsigned __int128 u128;
 #define SLOT_COUNT 9u          /* segment pick of draw i (multi-segment filters only)     */
 
 static const double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
+static const double LOG2PI = 0x1.d67f1c864beb5p+0;
 static const double INV_LN2 = 0x1.71547652b82fep+0;
 static const double LN2_HI = 0x1.62e42fee00000p-1;
 static const double LN2_LO = 0x1.a39ef35793c76p-33;
@@ -711,4 +712,37 @@ int orc_log_likelihood_batch(int model, const double* raw /*[n_theta][nraw]*/, i
         orc_filter_destroy(f);
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* exact scalar Kalman filter  src/kalman_filter.jl:29-53 (step), :55-70 (loop)           */
+/* raw = (A,B,Q,R,x0,sigma0).  predict_first != 0 is the literal reference loop (predict   */
+/* before the first update); 0 starts from x_1 ~ N(x0, sigma0) like bootstrap_filter.      */
+/* out = (x_T, Sigma_T, logZ).  Operation order is part of the spec (no fma).              */
+/* ------------------------------------------------------------------------------------ */
+void orc_kalman_log_likelihood(const double* raw, const double* y, int64_t T, int predict_first, double out[3]) {
+    const double A = raw[0], B = raw[1], Q = raw[2], R = raw[3];
+    double x = raw[4], S = raw[5], logZ = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        if (predict_first || t > 0) { x = A * x; S = (A * A) * S + Q; }           /* :186-187 */
+        const double s = (B * B) * S + R, dy = y[t] - B * x;                      /* :189-190 */
+        const double K = S * B, inv = 1.0 / s;
+        x = x + (K * inv) * dy;                                                   /* :193 */
+        S = S - (K * K) * inv;                                                    /* :194 */
+        logZ += -0.5 * (LOG2PI + orc_log(s) + (dy / s) * dy);                     /* :197-199 */
+    }
+    out[0] = x; out[1] = S; out[2] = logZ;
+}
+
+/* weighted mean and variance of every state coordinate under the current weights (plain sums) */
+void orc_filter_moments(const orc_filter* f, double* mean, double* var) {
+    const int64_t n = f->n;
+    double* w = (double*)malloc(8 * (size_t)n);
+    weights_dense(&f->W, w);
+    for (int c = 0; c < f->model.d; ++c) {
+        double m = 0.0, m2 = 0.0;
+        for (int64_t i = 0; i < n; ++i) { const double x = f->x[(size_t)c * n + i]; m += w[i] * x; m2 += w[i] * x * x; }
+        mean[c] = m; var[c] = m2 - m * m;
+    }
+    free(w);
 }

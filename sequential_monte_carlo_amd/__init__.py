@@ -6,6 +6,7 @@ host-side mirror of src/particles.jl, src/state_space_models.jl and src/smc_samp
 There is no CPU fallback: importing works anywhere, running a filter needs the GPU library.
 """
 from .distributions import LogNormal, Normal, TruncatedNormal, Uniform, product_distribution  # noqa: F401
+from .kalman_filter import log_likelihood_kalman  # noqa: F401
 from .models import (UCSV, LinearModel, StateSpaceModel, StochasticVolatility, UnivariateLinearGaussian,  # noqa: F401
                      simulate, unobserved_components, unobserved_components_stochastic_volatility)
 from .particles import (bootstrap_filter, bootstrap_filter_, log_likelihood, normalize, resample, reweight)  # noqa: F401

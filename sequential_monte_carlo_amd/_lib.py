@@ -18,7 +18,7 @@ FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
 EXPORTS = [
     "smc_create", "smc_destroy", "smc_set_params", "smc_set_streams", "smc_reseed", "smc_init", "smc_step",
     "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_copy_from", "smc_get_weights_raw", "smc_get_geometry",
-    "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_normalize", "smc_resample", "smc_simulate", "smc_model_dim",
+    "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_simulate", "smc_model_dim",
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
     "smc_host_box_muller", "smc_device_math", "smc_last_error", "smc_version",
 ]
@@ -66,6 +66,8 @@ def lib():
     L.smc_time_step_kernel.argtypes = [h, _dp, C.c_int64, C.c_int, _dp, _dp]
     L.smc_normalize.argtypes = [_dp, C.c_int64, _dp, _dp, _dp, C.c_int]
     L.smc_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, _i32p, C.c_int]
+    L.smc_kalman_log_likelihood.argtypes = [_dp, C.c_int64, _dp, C.c_int64, C.c_int, _dp, C.c_int]
+    L.smc_get_moments.argtypes = [h, _dp, _dp]
     L.smc_simulate.argtypes = [C.c_int, _dp, C.c_int64, C.c_uint64, _dp, _dp]
     L.smc_model_dim.argtypes = [C.c_int]
     L.smc_model_nraw.argtypes = [C.c_int]
@@ -122,6 +124,15 @@ def resample(w, ndraw=None, seed=0, stream=0, t=0, device=0):
     a = np.zeros(ndraw, dtype=np.int32)
     check(lib().smc_resample(_d(w), w.size, ndraw, seed, stream, t, a.ctypes.data_as(_i32p), device))
     return a
+
+
+def kalman_log_likelihood(raw, y, predict_first=False, device=0):
+    """Batched exact scalar Kalman filter (src/kalman_filter.jl:29-70): rows of (x_T, Sigma_T, logZ)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float64).reshape(-1, 6)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros((raw.shape[0], 3))
+    check(lib().smc_kalman_log_likelihood(_d(raw), raw.shape[0], _d(y), y.size, int(predict_first), _d(out), device))
+    return out
 
 
 def device_math(which, a, b=None, device=0):
@@ -209,6 +220,13 @@ class Handle:
         a = np.ascontiguousarray(a, dtype=np.int32)
         assert a.size == self.n_theta
         check(lib().smc_permute(self._h, a.ctypes.data_as(_i32p)))
+
+    def moments(self):
+        """filtered (mean, variance) of every state coordinate, [d][n_theta] each, computed on the device."""
+        m = np.zeros((self.d, self.n_theta))
+        v = np.zeros((self.d, self.n_theta))
+        check(lib().smc_get_moments(self._h, _d(m), _d(v)))
+        return m, v
 
     def copy_from(self, src, mask):
         m = np.ascontiguousarray(mask, dtype=np.uint8)

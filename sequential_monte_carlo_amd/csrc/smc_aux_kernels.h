@@ -45,6 +45,55 @@ __global__ void k_permute(FilterView v, int cur, int d, const int32_t* a, const 
     if (i == 0) v.logZ[th] = logZ_src[src];
 }
 
+// exact scalar Kalman filter, one lane per parameter row   kalman_filter.jl:29-70
+__global__ void k_kalman(const double* raw, int64_t ntheta, const double* y, int64_t T, int predict_first, double* out) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= ntheta) return;
+    const double A = raw[m * 6 + 0], B = raw[m * 6 + 1], Q = raw[m * 6 + 2], R = raw[m * 6 + 3];
+    double x = raw[m * 6 + 4], S = raw[m * 6 + 5], logZ = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        if (predict_first || t > 0) { x = A * x; S = (A * A) * S + Q; }
+        const double s = (B * B) * S + R, dy = y[t] - B * x;
+        const double K = S * B, inv = 1.0 / s;
+        x = x + (K * inv) * dy;
+        S = S - (K * K) * inv;
+        logZ += -0.5 * (0x1.d67f1c864beb5p+0 + sp_log(s) + (dy / s) * dy);
+    }
+    out[m * 3 + 0] = x; out[m * 3 + 1] = S; out[m * 3 + 2] = logZ;
+}
+
+// filtered moments: sum_i w_i x_i and sum_i w_i x_i^2 per (coordinate, theta).  grid (d, ntheta), one
+// workgroup each; w_i reconstructed from the fixed-point state exactly as k_dense_weights does.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_moments(FilterView v, int cur, double* mean, double* var) {
+    __shared__ double red[2][THREADS / WAVE];
+    const int c = blockIdx.x, th = blockIdx.y, tid = threadIdx.x;
+    const double K = v.last_K[th];
+    const uint64_t Dtot = v.last_D[th];
+    const double Dd = (double)Dtot * pow2i(v.SH - 48);
+    const uint64_t* C = v.C[cur] + (size_t)th * v.npad;
+    const double* x = v.x[cur] + ((size_t)c * v.ntheta + th) * v.npad;
+    double m = 0.0, m2 = 0.0;
+    for (int64_t i = tid; i < v.n; i += THREADS) {
+        const int b = (int)(i / v.seg), j = (int)(i % v.seg);
+        const uint64_t q = C[i] - (j ? C[i - 1] : 0);
+        const double dk = K - v.segk[cur][(size_t)th * v.nseg + b];
+        const double sc = (dk >= 0.0 && dk < 900.0) ? pow2i(-48 - (int)dk) : 0.0;
+        const double w = Dtot ? ((double)q * sc) / Dd : 0.0;
+        m += w * x[i];
+        m2 += w * x[i] * x[i];
+    }
+    for (int d = WAVE / 2; d >= 1; d >>= 1) { m += __shfl_xor(m, d, WAVE); m2 += __shfl_xor(m2, d, WAVE); }
+    if ((tid & (WAVE - 1)) == 0) { red[0][tid / WAVE] = m; red[1][tid / WAVE] = m2; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b2 = 0.0;
+        for (int w = 0; w < THREADS / WAVE; ++w) { a += red[0][w]; b2 += red[1][w]; }
+        mean[(size_t)c * v.ntheta + th] = a;
+        var[(size_t)c * v.ntheta + th] = b2 - a * a;
+    }
+}
+
 // accept step: slot th of dst <- slot th of src where mask[th]   grid (blocks, ntheta)
 __global__ void k_copy_slots(FilterView dst, int dcur, FilterView src, int scur, int d, const unsigned char* mask) {
     const int th = blockIdx.y;

@@ -527,7 +527,7 @@ extern "C" int smc_get_state(smc_handle h, double* x, double* w, int32_t* anc) {
     if (w) {
         int rc = emit_if_needed(h);
         if (rc) return rc;
-        if (!h->d_wdense) HIPCHK(dalloc(&h->d_wdense, (size_t)v.ntheta * v.n));
+        if (!h->d_wdense) HIPCHK(dalloc(&h->d_wdense, (size_t)v.ntheta * v.n + 2 * (size_t)h->d * v.ntheta));
         hipLaunchKernelGGL(k_dense_weights, dim3((unsigned)((v.n + 255) / 256), v.ntheta), dim3(256), 0, h->stream, v,
                            h->cur, h->d_wdense);
         HIPCHK(hipGetLastError());
@@ -688,6 +688,40 @@ extern "C" int smc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t 
     }
     (void)hipFree(d_w); (void)hipFree(d_C); (void)hipFree(d_a); (void)hipFree(d_st);
     return rc;
+}
+
+extern "C" int smc_kalman_log_likelihood(const double* raw, int64_t n_theta, const double* y, int64_t T, int predict_first,
+                                         double* out, int device) {
+    if (!raw || !y || !out || n_theta <= 0 || T <= 0) return fail(SMC_EINVAL, "smc_kalman_log_likelihood: bad argument");
+    HIPCHK(hipSetDevice(device));
+    double *d_raw = nullptr, *d_y = nullptr, *d_out = nullptr;
+    HIPCHK(dalloc(&d_raw, (size_t)n_theta * 6));
+    HIPCHK(dalloc(&d_y, (size_t)T));
+    HIPCHK(dalloc(&d_out, (size_t)n_theta * 3));
+    HIPCHK(hipMemcpy(d_raw, raw, (size_t)n_theta * 48, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_y, y, (size_t)T * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_kalman, dim3((unsigned)((n_theta + 63) / 64)), dim3(64), 0, 0, d_raw, n_theta, d_y, T, predict_first, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, d_out, (size_t)n_theta * 24, hipMemcpyDeviceToHost));
+    (void)hipFree(d_raw); (void)hipFree(d_y); (void)hipFree(d_out);
+    return SMC_OK;
+}
+
+extern "C" int smc_get_moments(smc_handle h, double* mean, double* var) {
+    if (!h || !mean || !var) return fail(SMC_EINVAL, "smc_get_moments: NULL argument");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_get_moments: filter not initialised");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    const size_t nout = (size_t)h->d * h->v.ntheta;
+    if (!h->d_wdense) HIPCHK(dalloc(&h->d_wdense, (size_t)h->v.ntheta * h->v.n + 2 * nout));
+    double *d_mean = h->d_wdense, *d_var = h->d_wdense + nout;
+    hipLaunchKernelGGL((k_moments<256>), dim3(h->d, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, d_mean, d_var);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(mean, d_mean, nout * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(var, d_var, nout * 8, hipMemcpyDeviceToHost));
+    return SMC_OK;
 }
 
 // ---- host-side helpers ---------------------------------------------------------------------------

@@ -80,6 +80,14 @@ class Particles:
     def __len__(self):
         return self._f.h.n_x
 
+    def moments(self):
+        """(mean, variance) of the filtered state under the current weights, computed on the device."""
+        m, v = self._f.h.moments()           # [d][n_theta]
+        m, v = m.T, v.T
+        if m.shape[-1] == 1:
+            m, v = m[..., 0], v[..., 0]
+        return (m[0], v[0]) if self._f.single else (m, v)
+
     def ancestors(self):
         _, _, a = self._f.h.state(want_w=False, want_anc=True)
         return a[0] if self._f.single else a

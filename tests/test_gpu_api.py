@@ -88,3 +88,46 @@ def test_smc2_online_hip_equals_oracle_backend():
     assert th == to and "[rejuvenating]" in th
     assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
     assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo))
+
+
+def test_batched_kalman_on_device(ob):
+    """exact scalar Kalman likelihood for many parameter rows; bit-exact vs the oracle,
+    and the value the particle estimate converges to."""
+    rng = np.random.default_rng(4)
+    ms = [smc.UnivariateLinearGaussian(A=rng.uniform(-0.9, 0.9), B=1.0, Q=rng.lognormal(), R=rng.lognormal(),
+                                       x0=rng.normal(), sigma0=rng.lognormal()) for _ in range(300)]
+    _, y = smc.simulate(ms[0], 150)
+    for pf in (False, True):
+        x, S, z = smc.log_likelihood_kalman(y, ms, predict_first=pf)
+        for k in (0, 1, 17, 299):
+            ox, oS, oz = ob.kalman_log_likelihood(ms[k].raw(), y, pf)
+            assert bits([x[k], S[k], z[k]]).tolist() == bits([ox, oS, oz]).tolist()
+    m = smc.UnivariateLinearGaussian(**LG)
+    _, y = smc.simulate(m, 100, seed=1998)
+    _, _, zk = smc.log_likelihood_kalman(y, m)
+    _, _, zp = smc.log_likelihood(1 << 18, y, m, seed=3)
+    assert abs(zp - zk) < 0.1
+
+
+def test_moments_on_device(ob):
+    """filtered mean / variance without copying the cloud to the host."""
+    m = smc.UnivariateLinearGaussian(**LG)
+    _, y = smc.simulate(m, 30, seed=1998)
+    x, w, logZ = smc.log_likelihood(5000, y, m, seed=8, seg=1024)
+    mean, var = x.moments()
+    xs, ws = np.asarray(x), np.asarray(w)
+    assert mean == pytest.approx(np.sum(ws * xs), rel=1e-12, abs=1e-13)
+    assert var == pytest.approx(np.sum(ws * xs * xs) - np.sum(ws * xs) ** 2, rel=1e-9)
+    f = ob.Filter(ob.LG1D, m.raw(), 5000, seg=1024, seed=8)
+    f.log_likelihood(y)
+    om, ov = f.moments()
+    assert mean == pytest.approx(om[0], rel=1e-12, abs=1e-13) and var == pytest.approx(ov[0], rel=1e-9)
+    # Kalman filtered mean within Monte-Carlo error
+    xk, Sk, _ = smc.log_likelihood_kalman(y, m)
+    assert abs(mean - xk) < 6 * np.sqrt(Sk / 5000) + 1e-3
+    u = smc.unobserved_components_stochastic_volatility(x0=3.0, gamma_eps=0.2, gamma_eta=0.2, log_sigma_eps=0.0, log_sigma_eta=0.0)
+    _, yu = smc.simulate(u, 20)
+    xu, wu, _ = smc.log_likelihood(1024, yu, [u, u], seed=2)
+    mu, vu = xu.moments()
+    assert mu.shape == (2, 3) and np.all(vu > 0)
+    assert np.allclose(mu, np.einsum("tn,tnd->td", np.asarray(wu), np.asarray(xu)), rtol=1e-12)

@@ -180,3 +180,15 @@ def test_edge_cases(ob):
     assert lm == -np.inf and ess == 0.0
     lm2, _ = f.step(0.1)
     assert np.array_equal(f.state()[2], np.arange(64)) and np.isfinite(lm2)
+
+
+def test_oracle_kalman_matches_numpy_restatement(ob):
+    from oracle import kalman
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        raw = [rng.uniform(-0.95, 0.95), rng.uniform(0.5, 1.5), rng.lognormal(), rng.lognormal(), rng.normal(), rng.lognormal()]
+        y = rng.normal(size=60)
+        for pf in (False, True):
+            x, S, z = ob.kalman_log_likelihood(raw, y, pf)
+            rx, rS, rz = kalman.log_likelihood(y, *raw[:4], x0=raw[4], sigma0=raw[5], predict_first=pf)
+            assert z == pytest.approx(rz, rel=1e-12) and x == pytest.approx(rx, rel=1e-11) and S == pytest.approx(rS, rel=1e-11)
