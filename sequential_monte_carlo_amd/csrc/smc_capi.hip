@@ -232,8 +232,8 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
         TRY(hipMemsetAsync(v.C[b], 0, np * 8, h->stream));
     }
     for (int b = 0; b < 2; ++b) {
-        TRY(dalloc(&v.cnt[b], ns));
-        TRY(hipMemsetAsync(v.cnt[b], 0, ns * 4, h->stream));
+        TRY(dalloc(&v.cnt[b], ns * NCOPY));
+        TRY(hipMemsetAsync(v.cnt[b], 0, ns * NCOPY * 4, h->stream));
     }
     if (flags & SMC_FLAG_ANCESTORS) TRY(dalloc(&v.anc, np));
     TRY(dalloc(&v.logZ, nt));

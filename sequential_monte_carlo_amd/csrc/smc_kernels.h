@@ -25,6 +25,9 @@
 namespace smc {
 
 constexpr int WAVE = 64;
+// The children counts are kept in NCOPY partial copies on different cache lines / channels: the
+// device-scope atomics of all workgroups otherwise serialise on 16 lines (a 4 us drain at the kernel end).
+constexpr int NCOPY = 8;
 
 struct FilterView {
     int64_t n;        // particles per filter (Nx)
@@ -40,7 +43,8 @@ struct FilterView {
     uint64_t* segS[2];
     uint64_t* segS2hi[2];
     uint64_t* segS2lo[2];
-    uint32_t* cnt[2];        // [ntheta][nseg] children per segment, double-buffered by step parity
+    uint32_t* cnt[2];        // [NCOPY][ntheta][nseg] children per segment (partial counts, summed by the
+                             // reader), double-buffered by step parity
     int32_t* anc;            // [ntheta][npad] or nullptr
     double* logZ;            // [ntheta]
     double* last_logmu;      // [ntheta]  (logmu, ess, K, D) of the most recently emitted weights
@@ -433,10 +437,11 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
         }
     }
     if (sb == 0) {
-        for (int b = tid; b < v.nseg; b += THREADS) {
-            v.cnt[0][(size_t)th * v.nseg + b] = 0;
-            v.cnt[1][(size_t)th * v.nseg + b] = 0;
-        }
+        for (int b = tid; b < v.nseg; b += THREADS)
+            for (int c = 0; c < NCOPY; ++c) {
+                v.cnt[0][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
+                v.cnt[1][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
+            }
     }
     segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
 }
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
     SMC_STAMP(v, 3);
     __syncthreads();
     SMC_STAMP(v, 4);
-    unsigned int* out = v.cnt[t & 1] + (size_t)th * v.nseg;
+    unsigned int* out = v.cnt[t & 1] + ((size_t)(blockIdx.x & (NCOPY - 1)) * v.ntheta + th) * v.nseg;
     for (int b = tid; b < v.nseg; b += THREADS) {
         const unsigned int c = hist[b];
         if (c) atomicAdd(&out[b], c);
@@ -543,6 +548,7 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const unsigned int* cn = v.cnt[t & 1] + (size_t)th * v.nseg;
+    const size_t cstride = (size_t)v.ntheta * v.nseg;   // between the NCOPY partial copies
     const uint64_t* sS = v.segS[cur] + (size_t)th * v.nseg;
     const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1;
     uint64_t run = 0;
@@ -553,7 +559,10 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
         for (int e = 0; e < E; ++e) {
             const int b = tid * E + e;
             const bool in = b < v.nseg;
-            run += in ? cn[b] : 0u;
+            unsigned int cb = 0;
+            if (in)
+                for (int c = 0; c < NCOPY; ++c) cb += cn[b + c * cstride];
+            run += cb;
             L.off[b] = (unsigned int)run;
             L.S[b] = in ? sS[b] : 0;
         }
@@ -610,7 +619,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     unsigned int pre_cnt = 0;
     uint64_t pre_S = 0;
     if (pre && tid < v.nseg) {
-        pre_cnt = v.cnt[t & 1][(size_t)th * v.nseg + tid];
+#pragma unroll
+        for (int c = 0; c < NCOPY; ++c) pre_cnt += v.cnt[t & 1][((size_t)c * v.ntheta + th) * v.nseg + tid];
         pre_S = v.segS[cur][(size_t)th * v.nseg + tid];
     }
     // (2) the 64-bit pick numbers of this thread's children
@@ -636,7 +646,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         alive = SMC_ABL(v, 5) ? 1u : offsets_prologue<THREADS>(v, cur, th, t, L, pre, pre_cnt, pre_S);
         SMC_STAMP(v, 1);
         if (sb == 0) {   // the counts of step t+1 accumulate into the other buffer: clear it
-            for (int b = tid; b < v.nseg; b += THREADS) v.cnt[(t + 1) & 1][(size_t)th * v.nseg + b] = 0;
+            for (int b = tid; b < v.nseg; b += THREADS)
+                for (int c = 0; c < NCOPY; ++c) v.cnt[(t + 1) & 1][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
         }
         // the children of this workgroup are consecutive, hence their segments form a range
         // [b_lo, b_hi] (usually 1-3 segments): find it once (uniform search), then every child
