@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["dt"])
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -68,10 +68,15 @@ def main():
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        if args.dist_backend == "nccl":   # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from sequential_monte_carlo_amd import _lib as L
 
+    if args.workload == "dt":
+        return bench_density_tempered(args, rank, local_rank, world, dist, torch)
     model, raw, nth, nx, T, desc = WORKLOADS[args.workload]
     _, y = L.simulate(model, raw if model != 3 else UC, T, 1998)
     if args.workload == "c5":
@@ -187,6 +192,65 @@ def main():
         }
         print(json.dumps(out))
     h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_density_tempered(args, rank, local_rank, world, dist, torch):
+    """Whole sampler: density_tempered (src/smc_samplers.jl:222-281) on the README's LG model
+    (README.md:81-98): N_theta = 512 per GPU x Nx = 1024, T = 200, chain = 3, ess_threshold = 0.5.
+    A "step" is one complete run; every executed inner particle-step is counted."""
+    import io
+    import sequential_monte_carlo_amd as smc
+    from sequential_monte_carlo_amd.distributed import ThetaComm
+    on_gpu = dist is not None and args.dist_backend == "nccl"
+    comm = None
+    if dist is not None:
+        comm = ThetaComm(dist, device=torch.device("cuda", local_rank) if on_gpu else None)
+    dev = local_rank if on_gpu else 0
+    M, N, T, chain = 512 * world, 1024, 200, 3
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(A=0.5, B=1.0, Q=0.9, R=0.8), T, seed=1998)
+    prior = smc.product_distribution([smc.TruncatedNormal(0, 1, -1, 1), smc.LogNormal(), smc.LogNormal()])
+
+    def mod(th):
+        return smc.UnivariateLinearGaussian(A=th[0], B=1.0, Q=th[1], R=th[2])
+
+    backend = smc.smc_samplers.HipBackend(device=dev)
+
+    def raw_fn(th):   # vectorised theta -> (A,B,Q,R,x0,sigma0) rows of the same model
+        m = th.shape[0]
+        return 1, np.column_stack([th[:, 0], np.ones(m), th[:, 1], th[:, 2], np.zeros(m), np.ones(m)])
+
+    def run(seed):
+        s = smc.SMC(N, M, mod, prior, chain, 0.5, seed=seed, backend=backend, comm=comm, raw_fn=raw_fn)
+        stages = smc.density_tempered(s, y, verbose=False, out=io.StringIO())
+        return s, stages
+
+    for k in range(args.warmup):
+        run(100 + k)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    psteps = 0
+    for k in range(args.steps):
+        s, stages = run(k + 1)
+        psteps += s.psteps
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "particle-steps/sec", "value": psteps / elapsed, "unit": "particle-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "density_tempered LG (README.md:81-98) Ntheta=%d (512/GPU) x Nx=1024 T=200 chain=3" % M,
+                       "stages_last_run": len(stages), "psteps_per_run": s.psteps, "posterior_mean": [float(v) for v in smc.expected_parameters(s)]},
+            "roofline": None, "cpu_baseline": None}))
+    backend.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -21,6 +21,13 @@ class Normal:
     def insupport(self, x):
         return math.isfinite(x)
 
+    def logpdf_v(self, x):
+        z = (x - self.mu) / self.sigma
+        return -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma)
+
+    def insupport_v(self, x):
+        return np.isfinite(x)
+
 
 class TruncatedNormal:
     """TruncatedNormal(mu, sigma, lo, hi)"""
@@ -43,6 +50,14 @@ class TruncatedNormal:
     def insupport(self, x):
         return self.lo <= x <= self.hi
 
+    def insupport_v(self, x):
+        return (x >= self.lo) & (x <= self.hi)
+
+    def logpdf_v(self, x):
+        z = (x - self.mu) / self.sigma
+        out = -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma) - self._logz
+        return np.where(self.insupport_v(x), out, -np.inf)
+
 
 class LogNormal:
     def __init__(self, mu=0.0, sigma=1.0):
@@ -60,6 +75,15 @@ class LogNormal:
     def insupport(self, x):
         return x > 0 and math.isfinite(x)
 
+    def insupport_v(self, x):
+        return (x > 0) & np.isfinite(x)
+
+    def logpdf_v(self, x):
+        ok = self.insupport_v(x)
+        xs = np.where(ok, x, 1.0)
+        z = (np.log(xs) - self.mu) / self.sigma
+        return np.where(ok, -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma) - np.log(xs), -np.inf)
+
 
 class Uniform:
     def __init__(self, lo=0.0, hi=1.0):
@@ -74,12 +98,37 @@ class Uniform:
     def insupport(self, x):
         return self.lo <= x <= self.hi
 
+    def insupport_v(self, x):
+        return (x >= self.lo) & (x <= self.hi)
+
+    def logpdf_v(self, x):
+        return np.where(self.insupport_v(x), -math.log(self.hi - self.lo), -np.inf)
+
+
+def _vec(f):
+    return np.vectorize(f, otypes=[float])
+
 
 class Product:
     """product_distribution([...]): independent components, theta is a vector."""
 
     def __init__(self, parts):
         self.parts = list(parts)
+
+    # vectorised over an [M, d] array of parameter particles (same arithmetic as the scalar methods)
+    def logpdf_many(self, thetas):
+        thetas = np.asarray(thetas, dtype=np.float64)
+        out = np.zeros(thetas.shape[0])
+        for k, p in enumerate(self.parts):
+            out = out + (p.logpdf_v(thetas[:, k]) if hasattr(p, "logpdf_v") else _vec(p.logpdf)(thetas[:, k]))
+        return out
+
+    def insupport_many(self, thetas):
+        thetas = np.asarray(thetas, dtype=np.float64)
+        ok = np.ones(thetas.shape[0], dtype=bool)
+        for k, p in enumerate(self.parts):
+            ok &= np.array([p.insupport(float(t)) for t in thetas[:, k]]) if not hasattr(p, "insupport_v") else p.insupport_v(thetas[:, k])
+        return ok
 
     def __len__(self):
         return len(self.parts)

@@ -20,6 +20,17 @@ from . import _lib
 from .models import params_matrix
 
 
+class RawModels:
+    """A batch of models of one family given directly as parameter rows (see SMC(raw_fn=...))."""
+
+    def __init__(self, model_id, raw):
+        self.model_id, self.rows = int(model_id), np.ascontiguousarray(raw, dtype=np.float64)
+
+
+def _rows(models):
+    return (models.model_id, models.rows) if isinstance(models, RawModels) else params_matrix(models)
+
+
 # ---- filter backends ---------------------------------------------------------------------------
 class HipBackend:
     """Runs the batched inner filters on one GPU through the C ABI (no CPU fallback)."""
@@ -38,14 +49,14 @@ class HipBackend:
         return h
 
     def log_likelihood(self, models, N, y, seed, streams, key="prop"):
-        mid, raw = params_matrix(models)
+        mid, raw = _rows(models)
         h = self._handle(key, mid, raw.shape[0], N, seed)
         h.set_params(raw)
         h.set_streams(streams)
         return h.log_likelihood(y), h
 
     def init(self, models, N, y1, seed, streams, key="main"):
-        mid, raw = params_matrix(models)
+        mid, raw = _rows(models)
         h = self._handle(key, mid, raw.shape[0], N, seed)
         h.set_params(raw)
         h.set_streams(streams)
@@ -62,8 +73,12 @@ class SMC:
     N state particles per filter, M parameter particles.  `model` maps a parameter vector to a
     StateSpaceModel (the reference's closure smc.model(theta))."""
 
-    def __init__(self, N, M, model, prior, chain, ess_threshold, min_ar=-1.0, seed=1, backend=None, comm=None):
+    def __init__(self, N, M, model, prior, chain, ess_threshold, min_ar=-1.0, seed=1, backend=None, comm=None,
+                 raw_fn=None):
+        """raw_fn (optional): vectorised shortcut for `model`: maps an [m, d_theta] array to (model_id, [m, n_raw]
+        parameter rows) without building m model objects per evaluation."""
         self.N, self.M, self.model, self.prior, self.chain = int(N), int(M), model, prior, int(chain)
+        self.raw_fn = raw_fn
         self.rng = np.random.default_rng(seed)
         self.seed = int(seed)
         self.theta = np.array([np.atleast_1d(prior.rand(self.rng)) for _ in range(self.M)], dtype=np.float64)
@@ -91,9 +106,15 @@ class SMC:
     def _gather(self, local):
         return local if self.comm is None else self.comm.all_gather(local)
 
+    def _models(self, thetas):
+        """smc.model(theta[m]) for a block of parameter particles (objects, or parameter rows via raw_fn)."""
+        if self.raw_fn is not None:
+            return RawModels(*self.raw_fn(np.asarray(thetas, dtype=np.float64)))
+        return [self.model(th) for th in thetas]
+
     def _filter_all(self, thetas, y, key="prop"):
         """logZ[m] = log_likelihood(N, y, model(theta[m])) for every m: ONE batched GPU call per rank."""
-        models = [self.model(th) for th in thetas[self.lo:self.hi]]
+        models = self._models(thetas[self.lo:self.hi])
         local, h = self.backend.log_likelihood(models, self.N, np.asarray(y, dtype=np.float64), self._next_seed(),
                                                self._streams(), key=key)
         self.psteps += self.M * self.N * len(y)
@@ -145,7 +166,7 @@ def random_walk_kernel(theta):
     else:
         sigma = (2.83 ** 2 / d) * cov + 1e-10 * np.eye(d)
     L = np.linalg.cholesky(sigma)
-    return lambda x, scale, rng: x + math.sqrt(scale) * (L @ rng.standard_normal(d))
+    return lambda x, scale, rng: x + math.sqrt(scale) * (L @ rng.standard_normal(d))   # MvNormal(x, scale*Sigma)
 
 
 def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
@@ -156,20 +177,22 @@ def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
     accepted = np.zeros(smc.M, dtype=bool)
     if verbose:
         out.write("\t[rejuvenating]")
+    many = hasattr(smc.prior, "logpdf_many")
     for c in range(smc.chain):
         prop = np.array([kernel(smc.theta[m], scales[c], smc.rng) for m in range(smc.M)])
-        ok = np.array([smc.prior.insupport(p) for p in prop])
         u = smc.rng.random(smc.M)
+        if many:
+            ok = smc.prior.insupport_many(prop)
+            lp_prop, lp_cur = smc.prior.logpdf_many(np.where(ok[:, None], prop, smc.theta)), smc.prior.logpdf_many(smc.theta)
+        else:
+            ok = np.array([smc.prior.insupport(p) for p in prop])
+            lp_prop = np.array([smc.prior.logpdf(p) if o else -math.inf for p, o in zip(prop, ok)])
+            lp_cur = np.array([smc.prior.logpdf(q) for q in smc.theta])
         safe = np.where(ok[:, None], prop, smc.theta)   # out-of-support proposals are never accepted
         logZ_prop, hprop = smc._filter_all(safe, y)
-        acc = np.zeros(smc.M, dtype=bool)
-        for m in range(smc.M):
-            if not ok[m]:
-                continue
-            lp_prop, lp_cur = smc.prior.logpdf(prop[m]), smc.prior.logpdf(smc.theta[m])
-            acc_ratio = xi * (logZ_prop[m] - smc.logZ[m]) + (lp_prop - lp_cur)
-            if logZ_prop[m] + lp_prop > -math.inf and math.log(u[m]) < acc_ratio:
-                acc[m] = True
+        acc_ratio = xi * (logZ_prop - smc.logZ) + (lp_prop - lp_cur)
+        with np.errstate(divide="ignore"):
+            acc = ok & (logZ_prop + lp_prop > -math.inf) & (np.log(u) < acc_ratio)
         smc.theta[acc] = prop[acc]
         smc.logZ[acc] = logZ_prop[acc]
         if smc._main is not None and acc[smc.lo:smc.hi].any():
@@ -223,7 +246,7 @@ def smc2(smc, y):
     y = np.asarray(y, dtype=np.float64)
     if smc.comm is not None:
         raise NotImplementedError("online smc2 with theta sharding moves x-clouds between GPUs (SURVEY 8f.2)")
-    models = [smc.model(th) for th in smc.theta]
+    models = smc._models(smc.theta)
     logmu, smc._main = smc.backend.init(models, smc.N, float(y[0]), smc._next_seed(), smc._streams(), key="main")
     smc.psteps += smc.M * smc.N
     smc.logZ = np.asarray(logmu, dtype=np.float64).copy()
@@ -243,7 +266,7 @@ def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
         rejuvenate_(smc, y[: t - 1], 1.0, verbose, out)
         _exchange(smc, y[: t - 1], verbose, out)
     logw = np.log(smc.omega)
-    smc._main.set_params(params_matrix([smc.model(th) for th in smc.theta])[1])
+    smc._main.set_params(_rows(smc._models(smc.theta))[1])
     lik, _ = smc._main.step(float(y[t - 1]))
     smc.psteps += smc.M * smc.N
     logw = logw + lik
@@ -262,7 +285,7 @@ def _exchange(smc, y, verbose, out):
             smc.N *= 2
             if verbose:
                 out.write("\t%d particles added" % smc.N)
-            models = [smc.model(th) for th in smc.theta]
+            models = smc._models(smc.theta)
             new_logZ, h = smc.backend.log_likelihood(models, smc.N, y, smc._next_seed(), smc._streams(), key="main")
             smc.psteps += smc.M * smc.N * len(y)
             smc._main = h

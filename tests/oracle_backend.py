@@ -5,7 +5,7 @@ bit for bit with the HIP backend on the GPU box.  Never imported by the product.
 import numpy as np
 
 from oracle import binding as ob
-from sequential_monte_carlo_amd.models import params_matrix
+from sequential_monte_carlo_amd.smc_samplers import _rows as params_matrix
 
 
 class OracleHandle:
