@@ -141,6 +141,7 @@ def main():
             kname = "k_resident"
         else:
             avg_ms, min_ms = h.time_step_kernel(y[: min(T, 400)], nsample=64)
+            ovh = h.event_overhead_ms(64)          # what an empty event bracket reads (reported, NOT subtracted)
             ms = avg_ms
             units = float(nth) * nx
             kname = "k_step"
@@ -155,6 +156,8 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "launch_ms": round(ms, 6), "algorithmic_bytes_per_launch": units * bytes_per_pstep}
+        if not h.resident:
+            roof["empty_event_bracket_ms"] = round(ovh, 6)   # rocprofv3's kernel-only average is ~2 us below launch_ms
 
     # ---- CPU baseline: the oracle (scalar port of particles.jl), bounded sample -----------------
     cpu = None

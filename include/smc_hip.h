@@ -89,6 +89,9 @@ int smc_synchronize(smc_handle h);
  * `nsample` evenly spaced k_step launches with HIP events on the handle's stream; returns the
  * average / minimum bracketed duration of ONE k_step launch in milliseconds. */
 int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, int nsample, double* avg_ms, double* min_ms);
+/* what an EMPTY HIP-event bracket measures on the handle's stream (average of nsample brackets with a
+ * trivial kernel before them): the fixed cost contained in every bracketed figure above. */
+int smc_event_overhead_ms(smc_handle h, int nsample, double* avg_ms);
 
 /* ---- stand-alone A1 / A2 ---------------------------------------------------------------------*/
 /* normalize(logw) -> (logmu, w, ess)                        src/particles.jl:5-15

@@ -18,7 +18,7 @@ FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
 EXPORTS = [
     "smc_create", "smc_destroy", "smc_set_params", "smc_set_streams", "smc_reseed", "smc_init", "smc_step",
     "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_copy_from", "smc_get_weights_raw", "smc_get_geometry",
-    "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_simulate", "smc_model_dim",
+    "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_event_overhead_ms", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_simulate", "smc_model_dim",
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
     "smc_host_box_muller", "smc_device_math", "smc_last_error", "smc_version",
 ]
@@ -64,6 +64,7 @@ def lib():
     L.smc_last_elapsed_ms.argtypes = [h, _dp]
     L.smc_synchronize.argtypes = [h]
     L.smc_time_step_kernel.argtypes = [h, _dp, C.c_int64, C.c_int, _dp, _dp]
+    L.smc_event_overhead_ms.argtypes = [h, C.c_int, _dp]
     L.smc_normalize.argtypes = [_dp, C.c_int64, _dp, _dp, _dp, C.c_int]
     L.smc_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, _i32p, C.c_int]
     L.smc_kalman_log_likelihood.argtypes = [_dp, C.c_int64, _dp, C.c_int64, C.c_int, _dp, C.c_int]
@@ -255,6 +256,11 @@ class Handle:
         a, m = C.c_double(), C.c_double()
         check(lib().smc_time_step_kernel(self._h, _d(y), y.size, nsample, C.byref(a), C.byref(m)))
         return a.value, m.value
+
+    def event_overhead_ms(self, nsample=64):
+        a = C.c_double()
+        check(lib().smc_event_overhead_ms(self._h, nsample, C.byref(a)))
+        return a.value
 
     def synchronize(self):
         check(lib().smc_synchronize(self._h))

@@ -509,6 +509,30 @@ extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, in
     return SMC_OK;
 }
 
+__global__ void k_nop() {}
+
+extern "C" int smc_event_overhead_ms(smc_handle h, int nsample, double* avg_ms) {
+    if (!h || !avg_ms || nsample < 1) return fail(SMC_EINVAL, "smc_event_overhead_ms: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<hipEvent_t> e0((size_t)nsample), e1((size_t)nsample);
+    for (int i = 0; i < nsample; ++i) { HIPCHK(hipEventCreate(&e0[i])); HIPCHK(hipEventCreate(&e1[i])); }
+    for (int i = 0; i < nsample; ++i) {
+        hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, h->stream);   // keeps the stream busy like the real loop does
+        HIPCHK(hipEventRecord(e0[i], h->stream));
+        HIPCHK(hipEventRecord(e1[i], h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double sum = 0.0;
+    for (int i = 0; i < nsample; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0[i], e1[i]));
+        sum += ms;
+        (void)hipEventDestroy(e0[i]); (void)hipEventDestroy(e1[i]);
+    }
+    *avg_ms = sum / nsample;
+    return SMC_OK;
+}
+
 extern "C" int smc_get_state(smc_handle h, double* x, double* w, int32_t* anc) {
     if (!h) return fail(SMC_EINVAL, "smc_get_state: NULL handle");
     if (!h->inited) return fail(SMC_ESTATE, "smc_get_state: filter not initialised");
