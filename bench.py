@@ -180,7 +180,7 @@ def main():
             cval = ns * nx * T / cdt
             sample = "first %d of %d filters (Nx=%d, T=%d), 1 thread" % (ns, nth, nx, T)
         cpu = {"value": round(cval, 1), "unit": "particle-steps/s", "cores": 1, "kind": "port", "sample": sample,
-               "seconds": round(cdt, 2)}
+               "seconds": round(cdt, 2), "julia": julia_baseline(nx)}
 
     if rank == 0:
         out = {
@@ -197,6 +197,21 @@ def main():
     h.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def julia_baseline(nx):
+    """time the repo's Julia restatement of particles.jl if (and only if) a julia with
+    Distributions + StatsBase is on this box; the reference package itself is never run."""
+    import shutil
+    import subprocess
+    if shutil.which("julia") is None:
+        return "julia unavailable"
+    try:
+        out = subprocess.run(["julia", os.path.join(ROOT, "julia", "reference_restatement.jl"), str(nx), "8"],
+                             capture_output=True, text=True, timeout=600)
+        return json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 else "julia failed: " + out.stderr[-200:]
+    except Exception as e:   # noqa: BLE001
+        return "julia failed: %s" % e
 
 
 def bench_density_tempered(args, rank, local_rank, world, dist, torch):

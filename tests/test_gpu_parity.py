@@ -378,3 +378,46 @@ def test_time_step_kernel_runs(L):
     avg, mn = h.time_step_kernel(y, nsample=8)
     assert 0 < mn <= avg < 5.0
     h.close()
+
+
+def test_randomized_configurations(L, ob):
+    """Fuzz: random model family / parameters / Nx / seg / n_theta / T / seed / streams, resident or
+    not -- every one bit-exact against the oracle (logZ, traces, states, weights, ancestors)."""
+    rng = np.random.default_rng(20260401)
+    for it in range(40):
+        model = int(rng.integers(1, 4))
+        seg = int(rng.choice([0, 256, 512, 1024, 2048]))
+        n = int(rng.integers(1, 9000))
+        if seg and rng.random() < 0.3:
+            n = int(rng.integers(1, seg + 1))            # single segment on purpose
+        nth = int(rng.integers(1, 4))
+        T = int(rng.integers(1, 9))
+        seed = int(rng.integers(1, 2**62))
+        flags = L.FLAG_ANCESTORS | (L.FLAG_NO_RESIDENT if rng.random() < 0.5 else 0)
+        if model == 1:
+            raws = np.column_stack([rng.uniform(-1, 1, nth), rng.uniform(0.5, 2, nth), rng.lognormal(0, 1, nth),
+                                    rng.lognormal(-1, 1.5, nth), rng.normal(0, 2, nth), rng.lognormal(0, 1, nth)])
+            sim = [0.7, 1.0, 1.0, 0.5, 0.0, 1.0]
+        elif model == 2:
+            raws = np.column_stack([rng.normal(-1, 1, nth), rng.uniform(-0.98, 0.98, nth), rng.lognormal(-1, 0.5, nth)])
+            sim = SV
+        else:
+            raws = np.column_stack([rng.uniform(0.02, 0.8, nth), rng.uniform(0.02, 0.8, nth), rng.normal(3, 2, nth),
+                                    rng.uniform(-2, 2, nth), rng.uniform(-2, 2, nth)])
+            sim = UC
+        _, y = ob.simulate(model, sim, T, int(rng.integers(1, 1000)))
+        streams = rng.integers(0, 2**32, nth, dtype=np.uint64).astype(np.uint32)
+        h = L.Handle(model, nth, n, seg=seg, seed=seed, flags=flags)
+        h.set_params(raws)
+        h.set_streams(streams)
+        logZ, lm, es = h.log_likelihood(y, trace=True)
+        x, w, a = h.state()
+        for th in range(nth):
+            f = ob.Filter(model, raws[th], n, seg=seg, seed=seed, stream=int(streams[th]))
+            z, olm, oes = f.log_likelihood(y, trace=True)
+            ox, ow, oa, _ = f.state()
+            ctx = (it, model, n, seg, nth, T, th)
+            assert bits([logZ[th]])[0] == bits([z])[0], ctx
+            assert same(lm[:, th], olm) and same(es[:, th], oes), ctx
+            assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa), ctx
+        h.close()
