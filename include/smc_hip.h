@@ -79,6 +79,14 @@ int smc_permute(smc_handle h, const int32_t* a /*[n_theta]*/);
  * filters, same geometry).  Value copy on the device; streams and parameters are not copied. */
 int smc_copy_from(smc_handle dst, smc_handle src, const uint8_t* mask /*[n_theta]*/);
 
+/* Moving whole filters between handles / GPUs (outer resample! of the online sampler when theta is
+ * sharded, src/smc_samplers.jl:74-84 + SURVEY 8e/8f.2): pack k slots (x cloud, weights, segment records,
+ * logZ) into / out of a caller-provided DEVICE buffer of k * smc_slot_bytes() bytes (e.g. a torch tensor
+ * that is then exchanged with an RCCL all-to-all).  idx: local slot indices, host array. */
+int smc_slot_bytes(smc_handle h, int64_t* bytes);
+int smc_pack_slots(smc_handle h, const int32_t* idx, int64_t k, void* device_buf);
+int smc_unpack_slots(smc_handle h, const int32_t* idx, int64_t k, const void* device_buf);
+
 /* raw fixed-point weight state (tests): C [n_theta][nseg*seg], m/S/S2hi/S2lo [n_theta][nseg] */
 int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo);
 int smc_get_geometry(smc_handle h, int* seg, int* nseg, int* d, int* resident);

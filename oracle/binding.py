@@ -53,6 +53,12 @@ def lib():
         L.orc_filter_reseed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
         L.orc_filter_set_params.argtypes = [C.c_void_p, _dp]
         L.orc_filter_copy_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_filter_state_words.restype = C.c_int64
+        L.orc_filter_state_words.argtypes = [C.c_void_p]
+        L.orc_filter_export.argtypes = [C.c_void_p, _u64p]
+        L.orc_filter_export.restype = None
+        L.orc_filter_import.argtypes = [C.c_void_p, _u64p]
+        L.orc_filter_import.restype = None
         L.orc_bootstrap_filter.restype = C.c_double
         L.orc_bootstrap_filter.argtypes = [C.c_void_p, C.c_double]
         L.orc_bootstrap_filter_step.restype = C.c_double
@@ -167,6 +173,16 @@ class Filter:
     def set_params(self, raw):
         raw = np.ascontiguousarray(raw, dtype=np.float64)
         assert lib().orc_filter_set_params(self._h, _d(raw)) == 0
+
+    def export_state(self):
+        buf = np.zeros(lib().orc_filter_state_words(self._h), dtype=np.uint64)
+        lib().orc_filter_export(self._h, buf.ctypes.data_as(_u64p))
+        return buf
+
+    def import_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint64)
+        assert buf.size == lib().orc_filter_state_words(self._h)
+        lib().orc_filter_import(self._h, buf.ctypes.data_as(_u64p))
 
     def copy_state_from(self, src):
         assert lib().orc_filter_copy_state(self._h, src._h) == 0

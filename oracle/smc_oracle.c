@@ -620,6 +620,33 @@ int orc_filter_copy_state(orc_filter* dst, const orc_filter* src) {
     return 0;
 }
 
+/* serialise the filter STATE (what orc_filter_copy_state copies) to / from 8-byte words: used by the tests of
+ * the theta-sharded online sampler to move filters between ranks */
+int64_t orc_filter_state_words(const orc_filter* f) {
+    const int64_t n = f->n, d = f->model.d, ns = f->W.nseg;
+    return d * n + n + n + ns * f->W.seg + 5 * ns + 8;
+}
+static uint64_t* put(uint64_t* b, const void* src, size_t words) { memcpy(b, src, 8 * words); return b + words; }
+static const uint64_t* get(const uint64_t* b, void* dst, size_t words) { memcpy(dst, b, 8 * words); return b + words; }
+void orc_filter_export(const orc_filter* f, uint64_t* b) {
+    const size_t n = (size_t)f->n, d = (size_t)f->model.d, ns = (size_t)f->W.nseg;
+    b = put(b, f->x, d * n); b = put(b, f->logw, n); b = put(b, f->a, n);
+    b = put(b, f->W.C, ns * (size_t)f->W.seg); b = put(b, f->W.kb, ns); b = put(b, f->W.S, ns);
+    b = put(b, f->W.S2hi, ns); b = put(b, f->W.S2lo, ns); b = put(b, f->W.Dcum, ns);
+    b = put(b, &f->W.K, 1); b = put(b, &f->W.Dtot, 1); b = put(b, &f->W.Rtot, 1);
+    b = put(b, &f->W.logmu, 1); b = put(b, &f->W.ess, 1);
+    uint64_t t = f->t; b = put(b, &t, 1);
+}
+void orc_filter_import(orc_filter* f, const uint64_t* b) {
+    const size_t n = (size_t)f->n, d = (size_t)f->model.d, ns = (size_t)f->W.nseg;
+    b = get(b, f->x, d * n); b = get(b, f->logw, n); b = get(b, f->a, n);
+    b = get(b, f->W.C, ns * (size_t)f->W.seg); b = get(b, f->W.kb, ns); b = get(b, f->W.S, ns);
+    b = get(b, f->W.S2hi, ns); b = get(b, f->W.S2lo, ns); b = get(b, f->W.Dcum, ns);
+    b = get(b, &f->W.K, 1); b = get(b, &f->W.Dtot, 1); b = get(b, &f->W.Rtot, 1);
+    b = get(b, &f->W.logmu, 1); b = get(b, &f->W.ess, 1);
+    uint64_t t; b = get(b, &t, 1); f->t = (uint32_t)t;
+}
+
 void orc_filter_reseed(orc_filter* f, uint64_t seed, uint32_t stream) { f->seed = seed; f->stream = stream; f->t = 0; }
 
 /* bootstrap_filter(N, y, model)  particles.jl:87-105  -> logmu */

@@ -17,7 +17,7 @@ FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
 # every symbol include/smc_hip.h declares
 EXPORTS = [
     "smc_create", "smc_destroy", "smc_set_params", "smc_set_streams", "smc_reseed", "smc_init", "smc_step",
-    "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_copy_from", "smc_get_weights_raw", "smc_get_geometry",
+    "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_copy_from", "smc_slot_bytes", "smc_pack_slots", "smc_unpack_slots", "smc_get_weights_raw", "smc_get_geometry",
     "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_event_overhead_ms", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_simulate", "smc_model_dim",
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
     "smc_host_box_muller", "smc_device_math", "smc_last_error", "smc_version",
@@ -37,6 +37,26 @@ class SmcError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname
+    as /opt/rocm's); whichever copy is loaded first serves both users, but if OUR library pulls in the system
+    copy first and torch initialises later, torch's bundled HSA runtime finds "No HIP GPUs".  So when a
+    torch wheel is installed we pre-load ITS runtime (a dlopen of one file, torch itself is not imported);
+    libsmchip.so's DT_NEEDED libamdhip64.so.7 then binds to it.  SMC_HIP_RUNTIME=system opts out."""
+    if os.environ.get("SMC_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:   # noqa: BLE001  (fall back to the system runtime)
+        pass
+
+
 def lib():
     """Load libsmchip.so (built by `__graft_entry__.build()` / csrc/Makefile). Fails loudly."""
     global _lib
@@ -45,6 +65,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SmcError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     h = C.c_void_p
     L.smc_create.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(h)]
@@ -59,6 +80,9 @@ def lib():
     L.smc_get_logZ.argtypes = [h, _dp, _dp]
     L.smc_permute.argtypes = [h, _i32p]
     L.smc_copy_from.argtypes = [h, h, C.POINTER(C.c_uint8)]
+    L.smc_slot_bytes.argtypes = [h, C.POINTER(C.c_int64)]
+    L.smc_pack_slots.argtypes = [h, _i32p, C.c_int64, C.c_void_p]
+    L.smc_unpack_slots.argtypes = [h, _i32p, C.c_int64, C.c_void_p]
     L.smc_get_weights_raw.argtypes = [h, _u64p, _dp, _u64p, _u64p, _u64p]
     L.smc_get_geometry.argtypes = [h, _ip, _ip, _ip, _ip]
     L.smc_last_elapsed_ms.argtypes = [h, _dp]
@@ -233,6 +257,20 @@ class Handle:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         assert m.size == self.n_theta
         check(lib().smc_copy_from(self._h, src._h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def slot_bytes(self):
+        b = C.c_int64()
+        check(lib().smc_slot_bytes(self._h, C.byref(b)))
+        return b.value
+
+    def pack_slots(self, idx, device_ptr):
+        """idx: local slot indices; device_ptr: integer address of a device buffer of len(idx)*slot_bytes() bytes."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        check(lib().smc_pack_slots(self._h, idx.ctypes.data_as(_i32p), idx.size, C.c_void_p(int(device_ptr))))
+
+    def unpack_slots(self, idx, device_ptr):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        check(lib().smc_unpack_slots(self._h, idx.ctypes.data_as(_i32p), idx.size, C.c_void_p(int(device_ptr))))
 
     def weights_raw(self):
         npad = self.nseg * self.seg

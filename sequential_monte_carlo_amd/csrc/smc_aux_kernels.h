@@ -94,6 +94,43 @@ __global__ __launch_bounds__(THREADS) void k_moments(FilterView v, int cur, doub
     }
 }
 
+// slot <-> packed buffer.  Packed slot layout in 8-byte words:
+//   x [d][npad] | C [npad] | kb,S,S2hi,S2lo [4][nseg] | logZ,last_logmu,last_ess,last_K,last_D [5]   (+ pad to even)
+__host__ __device__ inline int64_t slot_words(int d, int64_t npad, int nseg) {
+    const int64_t w = (int64_t)(d + 1) * npad + 4 * (int64_t)nseg + 5;
+    return (w + 1) & ~(int64_t)1;
+}
+template <bool PACK>
+__global__ void k_pack_slots(FilterView v, int cur, int d, const int32_t* idx, uint64_t* buf) {
+    const int s = blockIdx.y, th = idx[s];
+    const int64_t W = slot_words(d, v.npad, v.nseg);
+    uint64_t* b = buf + (size_t)s * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto mv = [&](uint64_t* slot_word, uint64_t* dev_word) {
+        if (PACK) *slot_word = *dev_word; else *dev_word = *slot_word;
+    };
+    if (i < v.npad) {
+        for (int c = 0; c < d; ++c) mv(b + (size_t)c * v.npad + i, (uint64_t*)(v.x[cur] + ((size_t)c * v.ntheta + th) * v.npad + i));
+        mv(b + (size_t)d * v.npad + i, v.C[cur] + (size_t)th * v.npad + i);
+    }
+    uint64_t* r = b + (size_t)(d + 1) * v.npad;
+    if (i < v.nseg) {
+        const size_t o = (size_t)th * v.nseg + i;
+        mv(r + i, (uint64_t*)(v.segk[cur] + o));
+        mv(r + v.nseg + i, v.segS[cur] + o);
+        mv(r + 2 * (size_t)v.nseg + i, v.segS2hi[cur] + o);
+        mv(r + 3 * (size_t)v.nseg + i, v.segS2lo[cur] + o);
+    }
+    if (i == 0) {
+        uint64_t* t = r + 4 * (size_t)v.nseg;
+        mv(t + 0, (uint64_t*)(v.logZ + th));
+        mv(t + 1, (uint64_t*)(v.last_logmu + th));
+        mv(t + 2, (uint64_t*)(v.last_ess + th));
+        mv(t + 3, (uint64_t*)(v.last_K + th));
+        mv(t + 4, v.last_D + th);
+    }
+}
+
 // accept step: slot th of dst <- slot th of src where mask[th]   grid (blocks, ntheta)
 __global__ void k_copy_slots(FilterView dst, int dcur, FilterView src, int scur, int d, const unsigned char* mask) {
     const int th = blockIdx.y;

@@ -619,6 +619,47 @@ extern "C" int smc_copy_from(smc_handle dst, smc_handle src, const uint8_t* mask
     return SMC_OK;
 }
 
+extern "C" int smc_slot_bytes(smc_handle h, int64_t* bytes) {
+    if (!h || !bytes) return fail(SMC_EINVAL, "smc_slot_bytes: NULL argument");
+    *bytes = slot_words(h->d, h->v.npad, h->v.nseg) * 8;
+    return SMC_OK;
+}
+
+static int pack_unpack(smc_handle h, const int32_t* idx, int64_t k, void* buf, bool pack) {
+    if (!h || k < 0 || (k > 0 && (!idx || !buf))) return fail(SMC_EINVAL, "smc_pack/unpack_slots: bad argument");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_pack/unpack_slots: filter not initialised");
+    if (k == 0) return SMC_OK;
+    for (int64_t i = 0; i < k; ++i)
+        if (idx[i] < 0 || idx[i] >= h->v.ntheta) return fail(SMC_EINVAL, "smc_pack/unpack_slots: index out of range");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    const FilterView& v = h->v;
+    const int64_t W = slot_words(h->d, v.npad, v.nseg);
+    const int64_t span = v.npad > v.nseg ? v.npad : v.nseg;
+    // a slot may be packed several times (a heavy theta-particle copied to many ranks): k can exceed
+    // n_theta, so go in chunks of the index buffer's capacity
+    for (int64_t k0 = 0; k0 < k; k0 += v.ntheta) {
+        const int64_t kc = k - k0 < v.ntheta ? k - k0 : v.ntheta;
+        HIPCHK(hipMemcpyAsync(h->d_perm, idx + k0, (size_t)kc * 4, hipMemcpyHostToDevice, h->stream));
+        const dim3 grid((unsigned)((span + 255) / 256), (unsigned)kc);
+        uint64_t* b = (uint64_t*)buf + (size_t)k0 * W;
+        if (pack)
+            hipLaunchKernelGGL((k_pack_slots<true>), grid, dim3(256), 0, h->stream, v, h->cur, h->d, h->d_perm, b);
+        else
+            hipLaunchKernelGGL((k_pack_slots<false>), grid, dim3(256), 0, h->stream, v, h->cur, h->d, h->d_perm, b);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return SMC_OK;
+}
+extern "C" int smc_pack_slots(smc_handle h, const int32_t* idx, int64_t k, void* device_buf) {
+    return pack_unpack(h, idx, k, device_buf, true);
+}
+extern "C" int smc_unpack_slots(smc_handle h, const int32_t* idx, int64_t k, const void* device_buf) {
+    return pack_unpack(h, idx, k, const_cast<void*>(device_buf), false);
+}
+
 extern "C" int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo) {
     if (!h) return fail(SMC_EINVAL, "smc_get_weights_raw: NULL handle");
     if (!h->inited) return fail(SMC_ESTATE, "smc_get_weights_raw: filter not initialised");

@@ -26,4 +26,48 @@ class ThetaComm:
             t = t.to(self.device)
         out = torch.empty(t.numel() * self.world, dtype=torch.float64, device=t.device)
         self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()
+        return out.cpu().numpy()          # .cpu() synchronises with the collective
+
+
+    # ---- online SMC^2 with sharded theta: resample!(smc) moves whole filters between ranks ---------------
+    def _export(self, h, idx):
+        import torch
+        if hasattr(h, "export_slots"):                      # test backends bring their own (CPU tensors)
+            return h.export_slots(idx)
+        words = h.slot_bytes() // 8
+        buf = torch.empty((len(idx), words), dtype=torch.int64, device=self.device if self.device is not None else "cuda")
+        if len(idx):
+            h.pack_slots(idx, buf.data_ptr())               # device -> device, no host staging
+        return buf
+
+    def _import(self, h, idx, buf):
+        if hasattr(h, "import_slots"):
+            return h.import_slots(idx, buf)
+        if len(idx):
+            h.unpack_slots(idx, buf.data_ptr())
+
+    def exchange_slots(self, h, a, M):
+        """After the outer resample drew global ancestors a[0..M): local slot m - lo of every rank becomes a
+        value copy of global slot a[m] (src/smc_samplers.jl:74-84), wherever that slot lives.  One
+        all-to-all of packed filter states (x cloud, weights, records) over xGMI."""
+        import torch
+        per = M // self.world
+        lo = self.rank * per
+        a = np.asarray(a, dtype=np.int64)
+        send_idx, send_counts = [], []
+        for r in range(self.world):
+            src = a[r * per:(r + 1) * per]
+            mine = src[(src // per) == self.rank] - lo
+            send_idx.append(mine)
+            send_counts.append(int(mine.size))
+        owners = a[lo:lo + per] // per
+        recv_counts = [int((owners == s).sum()) for s in range(self.world)]
+        dest_idx = np.concatenate([np.nonzero(owners == s)[0] for s in range(self.world)]).astype(np.int32)
+        sendbuf = self._export(h, np.concatenate(send_idx).astype(np.int32))
+        recvbuf = torch.empty((int(sum(recv_counts)), sendbuf.shape[1]), dtype=sendbuf.dtype, device=sendbuf.device)
+        self.dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=recv_counts, input_split_sizes=send_counts)
+        if recvbuf.is_cuda:
+            # the collective is asynchronous on RCCL's stream; the unpack kernel runs on the handle's own
+            # HIP stream, so make the received bytes final first
+            torch.cuda.synchronize(recvbuf.device)
+        self._import(h, dest_idx, recvbuf)

@@ -151,8 +151,9 @@ def resample_(smc):
     smc.logZ = smc.logZ[a].copy()
     if smc._main is not None:
         if smc.comm is not None:
-            raise NotImplementedError("online smc2 with theta sharding moves x-clouds between GPUs (SURVEY 8f.2)")
-        smc._main.permute(a.astype(np.int32))
+            smc.comm.exchange_slots(smc._main, a, smc.M)      # filters move between GPUs: one all-to-all
+        else:
+            smc._main.permute(a.astype(np.int32))
     return a
 
 
@@ -244,12 +245,10 @@ def density_tempered(smc, y, verbose=True, out=sys.stdout):
 def smc2(smc, y):
     """smc²(smc, y): initialisation at t = 1   smc_samplers.jl:288-301"""
     y = np.asarray(y, dtype=np.float64)
-    if smc.comm is not None:
-        raise NotImplementedError("online smc2 with theta sharding moves x-clouds between GPUs (SURVEY 8f.2)")
-    models = smc._models(smc.theta)
+    models = smc._models(smc.theta[smc.lo:smc.hi])
     logmu, smc._main = smc.backend.init(models, smc.N, float(y[0]), smc._next_seed(), smc._streams(), key="main")
     smc.psteps += smc.M * smc.N
-    smc.logZ = np.asarray(logmu, dtype=np.float64).copy()
+    smc.logZ = smc._gather(np.asarray(logmu, dtype=np.float64)).copy()
     _, smc.omega, smc.ess = _reweight(smc.logZ)
     smc.t = 1
     return smc
@@ -266,8 +265,9 @@ def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
         rejuvenate_(smc, y[: t - 1], 1.0, verbose, out)
         _exchange(smc, y[: t - 1], verbose, out)
     logw = np.log(smc.omega)
-    smc._main.set_params(_rows(smc._models(smc.theta))[1])
+    smc._main.set_params(_rows(smc._models(smc.theta[smc.lo:smc.hi]))[1])
     lik, _ = smc._main.step(float(y[t - 1]))
+    lik = smc._gather(np.asarray(lik, dtype=np.float64))
     smc.psteps += smc.M * smc.N
     logw = logw + lik
     smc.logZ = smc.logZ + lik
@@ -285,8 +285,9 @@ def _exchange(smc, y, verbose, out):
             smc.N *= 2
             if verbose:
                 out.write("\t%d particles added" % smc.N)
-            models = smc._models(smc.theta)
+            models = smc._models(smc.theta[smc.lo:smc.hi])
             new_logZ, h = smc.backend.log_likelihood(models, smc.N, y, smc._next_seed(), smc._streams(), key="main")
+            new_logZ = smc._gather(np.asarray(new_logZ, dtype=np.float64))
             smc.psteps += smc.M * smc.N * len(y)
             smc._main = h
             _, smc.omega, smc.ess = _reweight(np.asarray(new_logZ) - smc.logZ)

@@ -42,6 +42,18 @@ class OracleHandle:
             if mask[m]:
                 f.copy_state_from(src.f[m])
 
+    # movement of whole filters between ranks (same interface distributed.py uses for the HIP handle)
+    def export_slots(self, idx):
+        import torch
+        rows = [self.f[int(i)].export_state().view(np.int64) for i in idx]
+        w = int(ob.lib().orc_filter_state_words(self.f[0]._h))
+        return torch.from_numpy(np.stack(rows)) if rows else torch.empty((0, w), dtype=torch.int64)
+
+    def import_slots(self, idx, buf):
+        arr = buf.numpy().view(np.uint64)
+        for k, i in enumerate(idx):
+            self.f[int(i)].import_state(arr[k])
+
     def state(self):
         xs = [f.state() for f in self.f]
         return np.stack([x[0] for x in xs], axis=1), np.stack([x[1] for x in xs]), None

@@ -131,3 +131,59 @@ def test_moments_on_device(ob):
     mu, vu = xu.moments()
     assert mu.shape == (2, 3) and np.all(vu > 0)
     assert np.allclose(mu, np.einsum("tn,tnd->td", np.asarray(wu), np.asarray(xu)), rtol=1e-12)
+
+
+def test_pack_unpack_slots_roundtrip():
+    """smc_pack_slots / smc_unpack_slots through a torch device buffer (what the RCCL all-to-all moves)."""
+    import torch
+    from sequential_monte_carlo_amd import _lib as L
+    m = smc.UnivariateLinearGaussian(**LG)
+    _, y = smc.simulate(m, 8)
+    h = L.Handle(1, 5, 3000, seg=1024, seed=4)
+    h.set_params(np.tile(m.raw(), (5, 1)))
+    h.log_likelihood(y)
+    x0, w0, _ = h.state(want_anc=False)
+    z0, e0 = h.logZ()
+    idx = np.array([4, 4, 0, 2, 2, 2, 1], dtype=np.int32)            # duplicates, more items than slots
+    buf = torch.empty((idx.size, h.slot_bytes() // 8), dtype=torch.int64, device="cuda")
+    h.pack_slots(idx, buf.data_ptr())
+    g = L.Handle(1, 5, 3000, seg=1024, seed=9)
+    g.set_params(np.tile(m.raw(), (5, 1)))
+    g.init(y[0])
+    g.unpack_slots(np.array([0, 1, 2, 3, 4], dtype=np.int32), buf[[2, 6, 3, 0, 1]].contiguous().data_ptr())
+    x1, w1, _ = g.state(want_anc=False)
+    z1, e1 = g.logZ()
+    src = [0, 1, 2, 4, 4]
+    assert np.array_equal(bits(x1), bits(x0[:, src])) and np.array_equal(bits(w1), bits(w0[src]))
+    assert np.array_equal(bits(z1), bits(z0[src])) and np.array_equal(bits(e1), bits(e0[src]))
+    h.close(); g.close()
+
+
+def test_sharded_online_smc2_single_rank_rccl():
+    """The theta-sharded online sampler's exchange path on the GPU (RCCL all_to_all_single on device
+    buffers, world_size 1): identical to the unsharded run that uses smc_permute."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from sequential_monte_carlo_amd.distributed import ThetaComm
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 24, seed=1998)
+
+        def run(comm):
+            s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, seed=7, backend=smc.smc_samplers.HipBackend(), comm=comm)
+            smc.smc2(s, y)
+            for t in range(2, 25):
+                smc.smc2_step(s, y, t, verbose=False)
+            x, w, _ = s._main.state()
+            return s, x, w
+
+        s0, x0, w0 = run(None)
+        s1, x1, w1 = run(ThetaComm(dist, device=torch.device("cuda", 0)))
+        assert np.array_equal(bits(s0.theta), bits(s1.theta)) and np.array_equal(bits(s0.logZ), bits(s1.logZ))
+        assert np.array_equal(bits(x0), bits(x1)) and np.array_equal(bits(w0), bits(w1))
+    finally:
+        dist.destroy_process_group()

@@ -98,17 +98,34 @@ def test_smc2_online_runs_and_tracks():
     assert -1 < th[0] < 1 and th[1] > 0 and th[2] > 0
 
 
+def run_online(M=24, N=64, T=30, seed=5, comm=None):
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
+    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm)
+    smc.smc2(s, y)
+    moves = 0
+    for t in range(2, T + 1):
+        before = s._calls
+        smc.smc2_step(s, y, t, verbose=False)
+        moves += s._calls > before
+    x, w, _ = s._main.state()
+    return s, moves, x, w
+
+
 WORKER = r'''
 import os, sys, io, json
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 import numpy as np, torch.distributed as dist
 import sequential_monte_carlo_amd as smc
 from sequential_monte_carlo_amd.distributed import ThetaComm
-from test_samplers_cpu import run_dt
+from test_samplers_cpu import run_dt, run_online
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
 s, stages, text = run_dt(comm=ThetaComm(dist))
 assert (s.lo, s.hi) == ((0, 16) if dist.get_rank() == 0 else (16, 32))
 np.save(sys.argv[4] + ".%d.npy" % dist.get_rank(), np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages]]))
+# online SMC^2 with theta sharded: resample! moves whole filters between the two ranks (all-to-all)
+so, moves, x, w = run_online(comm=ThetaComm(dist))
+assert moves >= 1
+np.save(sys.argv[4] + ".online.%d.npy" % dist.get_rank(), np.concatenate([so.theta.ravel(), so.logZ, so.omega, x.ravel(), w.ravel()]))
 dist.destroy_process_group()
 '''
 
@@ -129,3 +146,14 @@ def test_theta_sharding_world_size_2_gloo(tmp_path):
     for r in range(2):
         got = np.load(str(tmp_path / "out") + ".%d.npy" % r)
         assert np.array_equal(got, ref)
+    # online SMC^2: the two halves of the filter states, concatenated, equal the single-process run
+    so, moves, x, w = run_online()
+    assert moves >= 1
+    head = np.concatenate([so.theta.ravel(), so.logZ, so.omega])
+    parts = [np.load(str(tmp_path / "out") + ".online.%d.npy" % r) for r in range(2)]
+    for p_ in parts:
+        assert np.array_equal(p_[:head.size], head)
+    d, M, N = x.shape[0], x.shape[1], x.shape[2]
+    xs = np.concatenate([p_[head.size:head.size + d * (M // 2) * N].reshape(d, M // 2, N) for p_ in parts], axis=1)
+    ws = np.concatenate([p_[head.size + d * (M // 2) * N:].reshape(M // 2, N) for p_ in parts], axis=0)
+    assert np.array_equal(xs, x) and np.array_equal(ws, w)
