@@ -195,6 +195,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     while (p2 < v.nseg) p2 <<= 1;
     v.nseg_p2 = p2;
     v.SH = table_shift_extra(v.npad);
+    v.want_s2 = 1;
 #ifdef SMC_ABLATE
     v.abl = h_abl_tmp;
     if (getenv("SMC_DBG") && !getenv("SMC_DBG_COUNT")) {
@@ -444,13 +445,16 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     h->v.trace_ess = want_trace ? h->d_tr_ess : nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     h->cur = 0;
+    h->v.want_s2 = want_trace ? 1 : 0;   // ess_t is read only through the traces; the last step always has it
     if (resident) {
         HIPCHK(do_resident(h, (int)T));
         h->cur = 0; h->t = (uint32_t)T; h->inited = true; h->emitted = true;
     } else {
+        if (T == 1) h->v.want_s2 = 1;
         HIPCHK(do_init(h, y[0]));
         h->t = 1; h->inited = true; h->emitted = false;
         for (int64_t t = 1; t < T; ++t) {
+            if (t == T - 1) h->v.want_s2 = 1;
             HIPCHK(do_count(h, (uint32_t)t, 1));
             HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
             h->cur ^= 1; h->t += 1;
@@ -458,6 +462,7 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
         rc = emit_if_needed(h);
         if (rc) return rc;
     }
+    h->v.want_s2 = 1;
     rc = finish_timing(h);
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     if (rc) return rc;

@@ -54,6 +54,8 @@ struct FilterView {
     double* trace_logmu;     // [T][ntheta] or nullptr
     double* trace_ess;       // [T][ntheta] or nullptr
     const double* y;         // [T] on device (log_likelihood) or nullptr
+    int want_s2;             // 1: accumulate sum q^2 (ESS) in this launch; 0: its consumer never reads it
+                             //    (log_likelihood discards ess, particles.jl:142: only the last step / traces need it)
     int abl;                 // ablation mask: always 0 in the product (profiling builds only, -DSMC_ABLATE)
     unsigned long long* dbg; // phase stamps [workgroup][8] (profiling builds only), else nullptr
 };
@@ -290,7 +292,7 @@ struct SegRec {
 
 // Cout: where the segment's inclusive sums go (global buffer or LDS), 16-B aligned.
 template <int THREADS, int NP>
-__device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_t* scr, uint64_t* Cout) {
+__device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_t* scr, uint64_t* Cout, bool want_s2) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     // exp(logw) = p 2^k for every particle: independent of the maximum, so it overlaps the reduction
@@ -321,12 +323,12 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
         for (int j = 0; j < 2; ++j) {
             const uint64_t qq = (kk[k][j] != DEAD) ? fix_weight_i(p[k][j], kk[k][j] - kbi, FIX_BITS) : 0;
             q[k][j] = qq;
-            s2 = add128(s2, sq128(qq));
+            if (want_s2) s2 = add128(s2, sq128(qq));
         }
         ps[k] = q[k][0] + q[k][1];
         incl[k] = wave_incl_scan(ps[k], lane);
     }
-    s2 = wave_sum128(s2);
+    if (want_s2) s2 = wave_sum128(s2);
     uint64_t* wtot = scr + NW;            // [NP][NW]   (scr[0..NW) is block_max's)
     uint64_t* w2 = scr + (NP + 1) * NW;   // [2][NW]
     if (lane == WAVE - 1) {
@@ -371,7 +373,7 @@ template <int THREADS, int NP>
 __device__ __forceinline__ void segment_epilogue(const FilterView& v, int nxt, int th, int sb, double (&lw)[NP][2],
                                                  uint64_t* scr) {
     uint64_t* Cout = v.C[nxt] + (size_t)th * v.npad + (size_t)sb * v.seg;
-    const SegRec rec = segment_normalize<THREADS, NP>(lw, scr, Cout);
+    const SegRec rec = segment_normalize<THREADS, NP>(lw, scr, Cout, v.want_s2 != 0);
     if (threadIdx.x == 0) {
         const size_t r = (size_t)th * v.nseg + sb;
         v.segk[nxt][r] = rec.kb;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
                 *reinterpret_cast<double2*>(xs + c * SEG + i0) = o;
             }
         }
-        const SegRec r = segment_normalize<THREADS, NP>(lw, scr, Cs);
+        const SegRec r = segment_normalize<THREADS, NP>(lw, scr, Cs, v.want_s2 != 0 || t == T - 1);
         S = r.S;
         if (tid == 0) {
             StepRec o;
