@@ -116,7 +116,7 @@ static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) 
 }
 namespace smc {
 hipError_t launch_count(const FilterView& v, int cur, uint32_t t, int emit_prev, hipStream_t s) {
-    constexpr int TH = 1024;   // fat workgroups: the table prologue is paid once per workgroup
+    constexpr int TH = 512;   // workgroup size of k_count (tuning: 256 / 512 / 1024)
     const int64_t npairs = (v.n + 1) >> 1;
     int64_t ncw = (npairs + 2 * TH - 1) / (2 * TH);   // one trip (2 pairs = 4 draws) per thread
     ncw = ncw < 1 ? 1 : (ncw > 1024 ? 1024 : ncw);

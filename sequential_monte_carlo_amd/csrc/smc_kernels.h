@@ -612,6 +612,12 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     const uint64_t* Cprev = v.C[cur] + (size_t)th * v.npad;
     const double* xprev = v.x[cur];
     uint64_t* scr;
+#ifdef SMC_ABLATE
+    if (SMC_ABL(v, 8) && (blockIdx.x & 8)) {   // experiment: stagger half of the workgroups by ~3.4 us
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     SMC_STAMP(v, 0);
 
     // Issue-early / use-late: every load whose address is known is issued BEFORE the random-number
@@ -670,12 +676,16 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         // (3) issue the loads of the first NSTAGE segments of the range (16 B per lane, coalesced);
         //     they land in LDS after the normals have been computed
         Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
+        const int nst = (b_hi - b_lo + 1) < NSTAGE ? (b_hi - b_lo + 1) : NSTAGE;
 #pragma unroll
-        for (int sg = 0; sg < NSTAGE; ++sg) {   // unconditional (clamped) loads keep stg[] in registers
-            const int bs = (b_lo + sg <= b_hi) ? b_lo + sg : b_lo;   // unneeded slots re-read b_lo (cache hit)
-            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)bs * SEG);
+        for (int sg = 0; sg < NSTAGE; ++sg) {
 #pragma unroll
-            for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
+            for (int k = 0; k < NP; ++k) stg[sg][k] = ulonglong2{0, 0};
+            if (sg < nst) {   // workgroup-uniform: only the segments of the range cost memory traffic
+                const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)(b_lo + sg) * SEG);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
+            }
         }
         blo = b_lo;
         int pos[NQ];
