@@ -28,6 +28,12 @@ constexpr int WAVE = 64;
 // The children counts are kept in NCOPY partial copies on different cache lines / channels: the
 // device-scope atomics of all workgroups otherwise serialise on 16 lines (a 4 us drain at the kernel end).
 constexpr int NCOPY = 8;
+// LDS copies of a segment's prefix sums are padded by two entries per 32: a binary search probes
+// index pos+s-1 with pos a multiple of 2s, so for s >= 32 EVERY lane's probe is = -1 (mod 32) and
+// (8-byte entries, 64 banks) lands on one bank pair -- up to 32-way conflicts.  With the pad the
+// probes of different 32-blocks fall on different banks; pairs stay 16-byte aligned.
+__host__ __device__ constexpr int lds_pad(int i) { return i + ((i >> 5) << 1); }
+__host__ __device__ constexpr int lds_padded_len(int n) { return n + (n >> 4); }
 
 struct FilterView {
     int64_t n;        // particles per filter (Nx)
@@ -291,7 +297,8 @@ struct SegRec {
 };
 
 // Cout: where the segment's inclusive sums go (global buffer or LDS), 16-B aligned.
-template <int THREADS, int NP>
+// PADDED: Cout is an LDS copy indexed through lds_pad().
+template <int THREADS, int NP, bool PADDED = false>
 __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_t* scr, uint64_t* Cout, bool want_s2) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -351,7 +358,7 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
         ulonglong2 cc;
         cc.x = excl + q[k][0];
         cc.y = cc.x + q[k][1];
-        *reinterpret_cast<ulonglong2*>(Cout + 2 * (tid + k * THREADS)) = cc;
+        *reinterpret_cast<ulonglong2*>(Cout + (PADDED ? lds_pad(2 * (tid + k * THREADS)) : 2 * (tid + k * THREADS))) = cc;
         basek += ktot;
     }
     SegRec rec;
@@ -534,7 +541,7 @@ __host__ __device__ inline size_t offs_lds_bytes(int nseg_p2, int threads, int n
 }
 __host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int np, bool multi) {
     const size_t base = (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;
-    return multi ? base + (size_t)nstage_for(2 * np * threads) * (2 * np * threads) * 8 : base;
+    return multi ? base + (size_t)nstage_for(2 * np * threads) * lds_padded_len(2 * np * threads) * 8 : base;
 }
 __device__ __forceinline__ OffsLds carve_offs(char* smem, int nseg_p2) {
     OffsLds o;
@@ -602,6 +609,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     constexpr int SEG = 2 * NP * THREADS;
     constexpr int NQ = 2 * NP;   // particles per thread
     constexpr int NSTAGE = nstage_for(SEG);
+    constexpr int SEGP = lds_padded_len(SEG);   // padded length of a staged segment in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = threadIdx.x;
     const int nxt = cur ^ 1;
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         for (int sg = 0; sg < NSTAGE; ++sg)
 #pragma unroll
             for (int k = 0; k < NP; ++k)
-                reinterpret_cast<ulonglong2*>(Cst)[sg * (SEG / 2) + tid + k * THREADS] = stg[sg][k];
+                *reinterpret_cast<ulonglong2*>(Cst + sg * SEGP + lds_pad(2 * (tid + k * THREADS))) = stg[sg][k];
         __syncthreads();   // staged segments visible
     }
     SMC_STAMP(v, 4);
@@ -763,13 +771,13 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         for (int i = 0; i < NQ; ++i) {
             const int r = bseg[i] - blo;
             far |= r >= NSTAGE;
-            sidx[i] = (r < NSTAGE ? r : 0) * SEG;
+            sidx[i] = (r < NSTAGE ? r : 0) * SEGP;
         }
 #pragma unroll
         for (int s = SEG >> 1; s >= 1; s >>= 1) {
             uint64_t val[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) val[i] = Cst[sidx[i] + pos[i] + s - 1];
+            for (int i = 0; i < NQ; ++i) val[i] = Cst[sidx[i] + lds_pad(pos[i] + s - 1)];
 #pragma unroll
             for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
         }

@@ -12,7 +12,7 @@ struct StepRec { double kb; uint64_t S, hi, lo; };
 
 template <int MODEL>
 __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int np) {
-    return (size_t)seg * 8 * (model_dim<MODEL>::value + 1) + scr_words(threads, np) * 8;
+    return (size_t)lds_padded_len(seg) * 8 + (size_t)seg * 8 * model_dim<MODEL>::value + scr_words(threads, np) * 8;
 }
 
 template <int MODEL, int THREADS, int NP>
@@ -20,9 +20,10 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* Cs = (uint64_t*)smem;                       // [SEG]
-    double* xs = (double*)(smem + (size_t)SEG * 8);       // [D][SEG]
-    uint64_t* scr = (uint64_t*)(smem + (size_t)SEG * 8 * (D + 1));
+    constexpr int SEGP = lds_padded_len(SEG);
+    uint64_t* Cs = (uint64_t*)smem;                       // [SEGP] padded against bank conflicts (lds_pad)
+    double* xs = (double*)(smem + (size_t)SEGP * 8);      // [D][SEG]
+    uint64_t* scr = (uint64_t*)(smem + (size_t)SEGP * 8 + (size_t)SEG * 8 * D);
     const int th = blockIdx.x, tid = threadIdx.x;
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
 #pragma unroll
             for (int s = SEG >> 1; s >= 1; s >>= 1) {
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) pos[i] += (Cs[pos[i] + s - 1] <= T2[i]) ? s : 0;
+                for (int i = 0; i < NQ; ++i) pos[i] += (Cs[lds_pad(pos[i] + s - 1)] <= T2[i]) ? s : 0;
             }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
                 *reinterpret_cast<double2*>(xs + c * SEG + i0) = o;
             }
         }
-        const SegRec r = segment_normalize<THREADS, NP>(lw, scr, Cs, v.want_s2 != 0 || t == T - 1);
+        const SegRec r = segment_normalize<THREADS, NP, true>(lw, scr, Cs, v.want_s2 != 0 || t == T - 1);
         S = r.S;
         if (tid == 0) {
             StepRec o;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         for (int c = 0; c < D; ++c)
             *reinterpret_cast<double2*>(v.x[0] + ((size_t)c * v.ntheta + th) * v.npad + i0) =
                 *reinterpret_cast<const double2*>(xs + c * SEG + i0);
-        *reinterpret_cast<ulonglong2*>(v.C[0] + (size_t)th * v.npad + i0) = *reinterpret_cast<const ulonglong2*>(Cs + i0);
+        *reinterpret_cast<ulonglong2*>(v.C[0] + (size_t)th * v.npad + i0) = *reinterpret_cast<const ulonglong2*>(Cs + lds_pad(i0));
         if (v.anc) {
             int2 o;
             o.x = anc[2 * k];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
 inline bool resident_supported(int model, int seg) {
     const int d = model_dim_rt(model);
     if (d < 0) return false;
-    return (size_t)seg * 8 * (d + 1) + 2048 <= 160 * 1024;
+    return (size_t)lds_padded_len(seg) * 8 + (size_t)seg * 8 * d + 2048 <= 160 * 1024;
 }
 
 }  // namespace smc
