@@ -33,7 +33,7 @@ constexpr int NCOPY = 8;
 // (8-byte entries, 64 banks) lands on one bank pair -- up to 32-way conflicts.  With the pad the
 // probes of different 32-blocks fall on different banks; pairs stay 16-byte aligned.
 __host__ __device__ constexpr int lds_pad(int i) { return i + ((i >> 5) << 1); }
-__host__ __device__ constexpr int lds_padded_len(int n) { return n + (n >> 4); }
+__host__ __device__ constexpr int lds_padded_len(int n) { return n + (n >> 4) + 8; }   // +8: staged neighbours start on different banks
 
 struct FilterView {
     int64_t n;        // particles per filter (Nx)
@@ -203,6 +203,8 @@ struct TableLds {
 __host__ __device__ inline size_t scr_words(int threads, int np) {
     return (size_t)((np + 3 > 4 ? np + 3 : 4) * (threads / WAVE) + 8);   // [red | wave totals ...]
 }
+// NOTE: every region below starts at nseg_p2*16 bytes so that k_step's two carves agree; the padded
+// Dcum (lds_pad) of k_count / k_finalize lives in a separate tail region (count_lds_bytes).
 __host__ __device__ inline size_t table_lds_bytes(int nseg_p2, int threads, int np) {
     return (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;   // sh padded to 8 B per entry
 }
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
     const int th = blockIdx.y, tid = threadIdx.x;
     const TableLds L = carve(smem, v.nseg_p2);
     unsigned int* hist = (unsigned int*)(L.scr + scr_words(THREADS, 1));   // [nseg_p2]
+    uint64_t* Dp = (uint64_t*)(hist + v.nseg_p2);                          // [lds_padded_len(nseg_p2)] padded copy of Dcum
     for (int b = tid; b < v.nseg_p2; b += THREADS) hist[b] = 0;
     SMC_STAMP(v, 0);
     const uint32_t stream = v.stream[th];
@@ -486,6 +489,8 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
     const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u);
     SMC_STAMP(v, 2);
     if (Dtot == 0) return;   // collapsed filter: counts stay 0, k_step falls back to identity
+    for (int b = tid; b < v.nseg_p2; b += THREADS) Dp[lds_pad(b)] = L.Dcum[b];
+    __syncthreads();
     for (int64_t pb = p0; pb < p1; pb += 2 * THREADS) {
         // two pairs (four draws) per thread per trip: independent LDS searches in flight
         uint64_t T1[4];
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
         int pos[4] = {0, 0, 0, 0};
         for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pos[i] += (L.Dcum[pos[i] + s - 1] <= T1[i]) ? s : 0;
+            for (int i = 0; i < 4; ++i) pos[i] += (Dp[lds_pad(pos[i] + s - 1)] <= T1[i]) ? s : 0;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
     SMC_STAMP(v, 5);
 }
 __host__ __device__ inline size_t count_lds_bytes(int nseg_p2, int threads) {
-    return table_lds_bytes(nseg_p2, threads, 1) + (size_t)nseg_p2 * 4;
+    return table_lds_bytes(nseg_p2, threads, 1) + (size_t)nseg_p2 * 4 + (size_t)lds_padded_len(nseg_p2) * 8 + 16;
 }
 
 // Offsets prologue of k_step (multi-segment): inclusive prefix sums of the children counts and
