@@ -33,6 +33,11 @@ constexpr int NCOPY = 8;
 // (8-byte entries, 64 banks) lands on one bank pair -- up to 32-way conflicts.  With the pad the
 // probes of different 32-blocks fall on different banks; pairs stay 16-byte aligned.
 __host__ __device__ constexpr int lds_pad(int i) { return i + ((i >> 5) << 1); }
+// A search keeps the padded position pp = lds_pad(pos) next to pos: pos is a multiple of 2s when the
+// level with stride s is probed, so the probe offset and the increment are compile-time constants.
+__host__ __device__ constexpr int lds_probe_off(int s) { return s >= 32 ? lds_pad(s - 32) + 31 : s - 1; }   // lds_pad(pos+s-1) - pp
+__host__ __device__ constexpr int lds_step_inc(int s) { return s >= 32 ? lds_pad(s) : s; }                  // lds_pad(pos+s) - pp
+__host__ __device__ constexpr int lds_unpad(int pp) { return pp - 2 * (pp / 34); }                          // inverse of lds_pad
 __host__ __device__ constexpr int lds_padded_len(int n) { return n + (n >> 4) + 8; }   // +8: staged neighbours start on different banks
 
 struct FilterView {
@@ -771,21 +776,24 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         // branch-free search in the staged copy (LDS); lanes whose segment is not staged keep a
         // harmless in-range index and redo the search in global memory below
         bool far = false;
-        int sidx[NQ];
+        int sidx[NQ], sidx0[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int r = bseg[i] - blo;
             far |= r >= NSTAGE;
             sidx[i] = (r < NSTAGE ? r : 0) * SEGP;
+            sidx0[i] = sidx[i];
         }
 #pragma unroll
         for (int s = SEG >> 1; s >= 1; s >>= 1) {
             uint64_t val[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) val[i] = Cst[sidx[i] + lds_pad(pos[i] + s - 1)];
+            for (int i = 0; i < NQ; ++i) val[i] = Cst[sidx[i] + lds_probe_off(s)];   // sidx carries the padded position
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
+            for (int i = 0; i < NQ; ++i) sidx[i] += (val[i] <= T2[i]) ? lds_step_inc(s) : 0;
         }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) pos[i] = lds_unpad(sidx[i] - sidx0[i]);
         if (__builtin_amdgcn_ballot_w64(far)) {   // rare: very uneven weights spread a workgroup over many segments
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {

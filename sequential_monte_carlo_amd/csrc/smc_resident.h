@@ -50,11 +50,16 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
                 mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], S, T2[2 * k + 1], lo);
                 pos[2 * k] = pos[2 * k + 1] = 0;
             }
+            int pp[NQ];   // padded position lds_pad(pos)
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) pp[i] = 0;
 #pragma unroll
             for (int s = SEG >> 1; s >= 1; s >>= 1) {
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) pos[i] += (Cs[lds_pad(pos[i] + s - 1)] <= T2[i]) ? s : 0;
+                for (int i = 0; i < NQ; ++i) pp[i] += (Cs[pp[i] + lds_probe_off(s)] <= T2[i]) ? lds_step_inc(s) : 0;
             }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) pos[i] = lds_unpad(pp[i]);
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const int own = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
