@@ -108,6 +108,23 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int /*lane*/) {
     v += dpp_u64z<0x143, 0xc>(v);
     return v;
 }
+// 32-bit inclusive prefix sum (the compiler folds each move into one v_add_u32_dpp)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += dpp_u32<0x111, 0xf>(0u, v);
+    v += dpp_u32<0x112, 0xf>(0u, v);
+    v += dpp_u32<0x114, 0xf>(0u, v);
+    v += dpp_u32<0x118, 0xf>(0u, v);
+    v += dpp_u32<0x142, 0xa>(0u, v);
+    v += dpp_u32<0x143, 0xc>(0u, v);
+    return v;
+}
+// inclusive prefix sum of values < 2^52 as two 26-bit limbs: 64 lanes x 2^26 fits 32 bits, so both
+// limb scans are 32-bit DPP adds (12 VALU instead of ~36 for the 64-bit scan)
+__device__ __forceinline__ uint64_t wave_incl_scan_52(uint64_t v) {
+    const uint32_t lo = wave_incl_scan_u32((uint32_t)v & 0x3ffffffu);
+    const uint32_t hi = wave_incl_scan_u32((uint32_t)(v >> 26));
+    return ((uint64_t)hi << 26) + lo;
+}
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
@@ -226,7 +243,7 @@ __device__ __forceinline__ TableLds carve(char* smem, int nseg_p2) {
 // those weights - the return value of normalize(), particles.jl:10,12 - and adds logmu to logZ.
 template <int THREADS>
 __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur, int th, const TableLds& L, bool emit,
-                                                   bool first_emit, uint32_t t_emit) {
+                                                   bool first_emit, uint32_t t_emit, uint64_t* Dpad = nullptr) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const size_t base = (size_t)th * v.nseg;
@@ -234,14 +251,36 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
     const uint64_t* sS = v.segS[cur] + base;
     double* red = (double*)L.scr;
 
-    double K = -inf();
-    for (int b = tid; b < v.nseg; b += THREADS) { const double k = sk[b]; K = k > K ? k : K; }
+    // one table entry per thread (the usual case): every record word is loaded up front, so the
+    // workgroup pays ONE global round trip instead of one per phase
+    const bool one = v.nseg_p2 <= THREADS;
+    double k1 = -inf();
+    uint64_t S1 = 0, hi1 = 0, lo1 = 0;
+    if (one && tid < v.nseg) {
+        k1 = sk[tid];
+        S1 = sS[tid];
+        if (emit) { hi1 = v.segS2hi[cur][base + tid]; lo1 = v.segS2lo[cur][base + tid]; }
+    }
+    double K = k1;
+    if (!one)
+        for (int b = tid; b < v.nseg; b += THREADS) { const double k = sk[b]; K = k > K ? k : K; }
     K = block_max<THREADS>(K, red);
 
     // blocked layout: thread owns E consecutive table entries
     const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1;
     uint64_t run = 0, rsum = 0;
-    if (tid * E < v.nseg_p2) {
+    if (one) {
+        if (tid < v.nseg_p2) {
+            int sh = 64;
+            if (tid < v.nseg) {
+                sh = seg_shift(K, k1, v.SH);
+                run = seg_Q(S1, sh);
+                if (emit) rsum = seg_R(hi1, lo1, sh, v.SH);
+            }
+            L.Dcum[tid] = run;
+            L.sh[tid] = sh;
+        }
+    } else if (tid * E < v.nseg_p2) {
         for (int e = 0; e < E; ++e) {
             const int b = tid * E + e;
             uint64_t Qb = 0;
@@ -274,7 +313,11 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
     }
     const uint64_t excl = off + incl - run;
     if (tid * E < v.nseg_p2)
-        for (int e = 0; e < E; ++e) L.Dcum[tid * E + e] += excl;
+        for (int e = 0; e < E; ++e) {
+            const uint64_t d = L.Dcum[tid * E + e] + excl;
+            L.Dcum[tid * E + e] = d;
+            if (Dpad) Dpad[lds_pad(tid * E + e)] = d;   // bank-staggered copy for the searches
+        }
     if (emit && tid == 0) {
         uint64_t Rtot = 0;
 #pragma unroll
@@ -322,6 +365,9 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
             const bool alive = lw_alive(l);
             double kq;
             p[k][j] = sp_exp_parts(alive ? l : 0.0, kq);
+            // keep the polynomial HERE (the compiler otherwise sinks it behind the barrier into
+            // divergent per-particle branches and re-materialises its constants in each of them)
+            asm volatile("" : "+v"(p[k][j]));
             kk[k][j] = alive ? (int)kq : DEAD;
             kloc = kk[k][j] > kloc ? kk[k][j] : kloc;
         }
@@ -335,12 +381,16 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     for (int k = 0; k < NP; ++k) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const uint64_t qq = (kk[k][j] != DEAD) ? fix_weight_i(p[k][j], kk[k][j] - kbi, FIX_BITS) : 0;
+            // fix_weight_i(p, k - kb, FIX_BITS), branch-free (same value: the clamp only acts where q = 0)
+            const int dk = (kk[k][j] != DEAD) ? kk[k][j] - kbi : -1024;
+            const int ek = dk > -(FIX_BITS + 8) ? FIX_BITS + dk : -8;
+            const uint64_t qv = d2bits(p[k][j] * pow2i(ek) + 0x1p52) & 0x000fffffffffffffULL;
+            const uint64_t qq = dk >= -(FIX_BITS + 2) ? qv : 0;
             q[k][j] = qq;
             if (want_s2) s2 = add128(s2, sq128(qq));
         }
         ps[k] = q[k][0] + q[k][1];
-        incl[k] = wave_incl_scan(ps[k], lane);
+        incl[k] = wave_incl_scan_52(ps[k]);   // q < 1.42 * 2^48: a pair sum is below 2^50
     }
     if (want_s2) s2 = wave_sum128(s2);
     uint64_t* wtot = scr + NW;            // [NP][NW]   (scr[0..NW) is block_max's)
@@ -491,11 +541,9 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
         r4[2 * u + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
     }
     SMC_STAMP(v, 1);
-    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u);
+    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u, Dp);
     SMC_STAMP(v, 2);
     if (Dtot == 0) return;   // collapsed filter: counts stay 0, k_step falls back to identity
-    for (int b = tid; b < v.nseg_p2; b += THREADS) Dp[lds_pad(b)] = L.Dcum[b];
-    __syncthreads();
     for (int64_t pb = p0; pb < p1; pb += 2 * THREADS) {
         // two pairs (four draws) per thread per trip: independent LDS searches in flight
         uint64_t T1[4];
@@ -514,11 +562,22 @@ __global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32
             ok[2 * u] = p < p1 && 2 * p < v.n;
             ok[2 * u + 1] = p < p1 && 2 * p + 1 < v.n;
         }
-        int pos[4] = {0, 0, 0, 0};
-        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
+        // the searches carry the padded position as a byte pointer into Dp (probe offsets and step
+        // increments are workgroup-uniform scalars)
+        const char* cp[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pos[i] += (Dp[lds_pad(pos[i] + s - 1)] <= T1[i]) ? s : 0;
+        for (int i = 0; i < 4; ++i) cp[i] = (const char*)Dp;
+        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
+            const int po = 8 * lds_probe_off(s), inc = 8 * lds_step_inc(s);
+            uint64_t val[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) val[i] = *reinterpret_cast<const uint64_t*>(cp[i] + po);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cp[i] += (val[i] <= T1[i]) ? inc : 0;
         }
+        int pos[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pos[i] = lds_unpad((int)(cp[i] - (const char*)Dp) >> 3);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (ok[i]) atomicAdd(&hist[pos[i]], 1u);
@@ -586,7 +645,7 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
             L.S[b] = in ? sS[b] : 0;
         }
     }
-    const uint64_t incl = wave_incl_scan(run, lane);
+    const uint64_t incl = wave_incl_scan_u32((uint32_t)run);   // counts: the total is n < 2^31
     uint64_t* wt = L.scr + 2 * NW;   // not the region block_max / the epilogue's first writes use
     if (lane == WAVE - 1) wt[wave] = incl;
     __syncthreads();
@@ -776,24 +835,27 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         // branch-free search in the staged copy (LDS); lanes whose segment is not staged keep a
         // harmless in-range index and redo the search in global memory below
         bool far = false;
-        int sidx[NQ], sidx0[NQ];
+        // pb carries the padded position as an LDS byte pointer: a probe is then one ds_read_b64
+        // with an immediate offset, no per-level address arithmetic
+        const char* pb[NQ];
+        const char* pb0[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int r = bseg[i] - blo;
             far |= r >= NSTAGE;
-            sidx[i] = (r < NSTAGE ? r : 0) * SEGP;
-            sidx0[i] = sidx[i];
+            pb0[i] = (const char*)(Cst + (r < NSTAGE ? r : 0) * SEGP);
+            pb[i] = pb0[i];
         }
 #pragma unroll
         for (int s = SEG >> 1; s >= 1; s >>= 1) {
             uint64_t val[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) val[i] = Cst[sidx[i] + lds_probe_off(s)];   // sidx carries the padded position
+            for (int i = 0; i < NQ; ++i) val[i] = *reinterpret_cast<const uint64_t*>(pb[i] + 8 * lds_probe_off(s));
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) sidx[i] += (val[i] <= T2[i]) ? lds_step_inc(s) : 0;
+            for (int i = 0; i < NQ; ++i) pb[i] += (val[i] <= T2[i]) ? 8 * lds_step_inc(s) : 0;
         }
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) pos[i] = lds_unpad(sidx[i] - sidx0[i]);
+        for (int i = 0; i < NQ; ++i) pos[i] = lds_unpad((int)(pb[i] - pb0[i]) >> 3);
         if (__builtin_amdgcn_ballot_w64(far)) {   // rare: very uneven weights spread a workgroup over many segments
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {

@@ -12,7 +12,7 @@ struct StepRec { double kb; uint64_t S, hi, lo; };
 
 template <int MODEL>
 __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int np) {
-    return (size_t)lds_padded_len(seg) * 8 + (size_t)seg * 8 * model_dim<MODEL>::value + scr_words(threads, np) * 8;
+    return (size_t)lds_padded_len(seg) * 8 * (1 + model_dim<MODEL>::value) + scr_words(threads, np) * 8;
 }
 
 template <int MODEL, int THREADS, int NP>
@@ -22,8 +22,8 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SEGP = lds_padded_len(SEG);
     uint64_t* Cs = (uint64_t*)smem;                       // [SEGP] padded against bank conflicts (lds_pad)
-    double* xs = (double*)(smem + (size_t)SEGP * 8);      // [D][SEG]
-    uint64_t* scr = (uint64_t*)(smem + (size_t)SEGP * 8 + (size_t)SEG * 8 * D);
+    double* xs = (double*)(smem + (size_t)SEGP * 8);      // [D][SEGP] padded the same way
+    uint64_t* scr = (uint64_t*)(smem + (size_t)SEGP * 8 + (size_t)SEGP * 8 * D);
     const int th = blockIdx.x, tid = threadIdx.x;
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
@@ -41,37 +41,39 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         if (t > 0) {
             // a = resample(weights); xp = x[a]: the NQ searches of a thread advance level by level
             uint64_t T2[NQ];
-            int pos[NQ];
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const u32x4 rw = draw(v.seed, (uint32_t)(tid + k * THREADS), stream, (uint32_t)t, SLOT_RESAMPLE);
                 uint64_t lo;
                 mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], S, T2[2 * k], lo);
                 mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], S, T2[2 * k + 1], lo);
-                pos[2 * k] = pos[2 * k + 1] = 0;
             }
-            int pp[NQ];   // padded position lds_pad(pos)
+            // the search carries the padded position as an LDS byte pointer (one ds_read_b64 with an
+            // immediate offset per probe); xs is padded like Cs, so the gather uses it as it stands
+            const char* pb[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) pp[i] = 0;
+            for (int i = 0; i < NQ; ++i) pb[i] = (const char*)Cs;
 #pragma unroll
             for (int s = SEG >> 1; s >= 1; s >>= 1) {
+                uint64_t val[NQ];
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) pp[i] += (Cs[pp[i] + lds_probe_off(s)] <= T2[i]) ? lds_step_inc(s) : 0;
+                for (int i = 0; i < NQ; ++i) val[i] = *reinterpret_cast<const uint64_t*>(pb[i] + 8 * lds_probe_off(s));
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) pb[i] += (val[i] <= T2[i]) ? 8 * lds_step_inc(s) : 0;
             }
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) pos[i] = lds_unpad(pp[i]);
+            const int last_p = lds_pad((int)v.n - 1);
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const int own = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
-                int a = S ? pos[i] : own;
-                a = a < v.n ? a : (int)v.n - 1;
-                anc[i] = a;
+                int ap = S ? (int)(pb[i] - (const char*)Cs) >> 3 : lds_pad(own);   // collapsed filter: identity
+                ap = ap < last_p ? ap : last_p;   // lds_pad is increasing: the clamp to n-1 commutes with it
+                anc[i] = ap;
 #pragma unroll
-                for (int c = 0; c < D; ++c) xp[i][c] = xs[c * SEG + a];
+                for (int c = 0; c < D; ++c) xp[i][c] = xs[c * SEGP + ap];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) anc[i] = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+            for (int i = 0; i < NQ; ++i) anc[i] = lds_pad(2 * (tid + (i >> 1) * THREADS) + (i & 1));
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
                 double2 o;
                 o.x = i0 < v.n ? xn[k][0][c] : 0.0;
                 o.y = (i0 + 1) < v.n ? xn[k][1][c] : 0.0;
-                *reinterpret_cast<double2*>(xs + c * SEG + i0) = o;
+                *reinterpret_cast<double2*>(xs + c * SEGP + lds_pad(i0)) = o;
             }
         }
         const SegRec r = segment_normalize<THREADS, NP, true>(lw, scr, Cs, v.want_s2 != 0 || t == T - 1);
@@ -119,12 +121,12 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
 #pragma unroll
         for (int c = 0; c < D; ++c)
             *reinterpret_cast<double2*>(v.x[0] + ((size_t)c * v.ntheta + th) * v.npad + i0) =
-                *reinterpret_cast<const double2*>(xs + c * SEG + i0);
+                *reinterpret_cast<const double2*>(xs + c * SEGP + lds_pad(i0));
         *reinterpret_cast<ulonglong2*>(v.C[0] + (size_t)th * v.npad + i0) = *reinterpret_cast<const ulonglong2*>(Cs + lds_pad(i0));
         if (v.anc) {
             int2 o;
-            o.x = anc[2 * k];
-            o.y = anc[2 * k + 1];
+            o.x = lds_unpad(anc[2 * k]);   // anc holds padded positions
+            o.y = lds_unpad(anc[2 * k + 1]);
             *reinterpret_cast<int2*>(v.anc + (size_t)th * v.npad + i0) = o;
         }
     }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
 inline bool resident_supported(int model, int seg) {
     const int d = model_dim_rt(model);
     if (d < 0) return false;
-    return (size_t)lds_padded_len(seg) * 8 + (size_t)seg * 8 * d + 2048 <= 160 * 1024;
+    return (size_t)lds_padded_len(seg) * 8 * (1 + d) + 2048 <= 160 * 1024;
 }
 
 }  // namespace smc
