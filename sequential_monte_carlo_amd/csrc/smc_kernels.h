@@ -620,9 +620,12 @@ __device__ __forceinline__ OffsLds carve_offs(char* smem, int nseg_p2) {
     return o;
 }
 // `pre`: this thread's (count, S) entry was loaded early by the caller (only when nseg_p2 <= THREADS).
+// rng[0], rng[1] (LDS): the segments the children jfirst and jlast come from, i.e. the first b with
+// off[b] > j (nseg-1 if there is none).  The thread that owns that table entry writes it - no search.
 template <int THREADS>
 __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, int cur, int th, uint32_t t, const OffsLds& L,
-                                                         bool pre, unsigned int pre_cnt, uint64_t pre_S) {
+                                                         bool pre, unsigned int pre_cnt, uint64_t pre_S, int* rng,
+                                                         unsigned int jfirst, unsigned int jlast) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const unsigned int* cn = v.cnt[t & 1] + (size_t)th * v.nseg;
@@ -648,6 +651,7 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
     const uint64_t incl = wave_incl_scan_u32((uint32_t)run);   // counts: the total is n < 2^31
     uint64_t* wt = L.scr + 2 * NW;   // not the region block_max / the epilogue's first writes use
     if (lane == WAVE - 1) wt[wave] = incl;
+    if (tid == 0) rng[0] = rng[1] = v.nseg - 1;
     __syncthreads();
     uint64_t off = 0, tot = 0;
 #pragma unroll
@@ -657,8 +661,16 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
         tot += x;
     }
     const unsigned int excl = (unsigned int)(off + incl - run);
-    if (tid * E < v.nseg_p2)
-        for (int e = 0; e < E; ++e) L.off[tid * E + e] += excl;
+    if (tid * E < v.nseg_p2) {
+        unsigned int below = excl;   // children before entry b
+        for (int e = 0; e < E; ++e) {
+            const unsigned int o = L.off[tid * E + e] + excl;
+            L.off[tid * E + e] = o;
+            if (below <= jfirst && jfirst < o) rng[0] = tid * E + e;
+            if (below <= jlast && jlast < o) rng[1] = tid * E + e;
+            below = o;
+        }
+    }
     __syncthreads();
     return (unsigned int)tot;
 }
@@ -718,53 +730,72 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         rr[2 * k + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
     }
 
+    // (3) speculative staging (NSTAGE = 3): children are segment-sorted, so the ancestors of the
+    //     children at positions [sb*SEG, (sb+1)*SEG) usually sit in segments sb-1..sb+1.  Their loads
+    //     are issued NOW, together with the counts; the range is checked once it is known (below).
+    constexpr bool SPEC = MULTI && NSTAGE == 3;
+    ulonglong2 stg[NSTAGE][NP];   // staging registers: NP 16-byte pieces per thread per staged segment
+    int spec_lo = 0;
+    if (SPEC) {
+        spec_lo = sb - 1 < 0 ? 0 : sb - 1;
+        spec_lo = spec_lo + NSTAGE > v.nseg ? (v.nseg - NSTAGE < 0 ? 0 : v.nseg - NSTAGE) : spec_lo;
+#pragma unroll
+        for (int sg = 0; sg < NSTAGE; ++sg) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) stg[sg][k] = ulonglong2{0, 0};
+            if (spec_lo + sg < v.nseg) {
+                const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)(spec_lo + sg) * SEG);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
+            }
+        }
+    }
+
     // alive = some weight is positive; otherwise the filter collapsed and ancestors are the identity
     uint64_t alive;
     uint64_t Sseg[NQ];
     int bseg[NQ];
     uint64_t* Cst = nullptr;   // staged segments [NSTAGE][SEG] (MULTI)
     int blo = 0;
-    ulonglong2 stg[NSTAGE][NP];   // staging registers: NP 16-byte pieces per thread per staged segment
     if (MULTI) {
         const OffsLds L = carve_offs(smem, v.nseg_p2);
         scr = L.scr;
-        alive = SMC_ABL(v, 5) ? 1u : offsets_prologue<THREADS>(v, cur, th, t, L, pre, pre_cnt, pre_S);
+        // the children of this workgroup are consecutive, hence their segments form a range
+        // [b_lo, b_hi] (usually 1-3 segments); every child then searches only inside it
+        const unsigned int jfirst = (unsigned int)seg0;
+        const int64_t jl = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - 1;
+        const unsigned int jlast = jl > seg0 ? (unsigned int)jl : jfirst;
+        int* rng = (int*)(L.scr + scr_words(THREADS, NP) - 8);   // tail words nobody else uses
+        alive = offsets_prologue<THREADS>(v, cur, th, t, L, pre, pre_cnt, pre_S, rng, jfirst, jlast);
         SMC_STAMP(v, 1);
         if (sb == 0) {   // the counts of step t+1 accumulate into the other buffer: clear it
             for (int b = tid; b < v.nseg; b += THREADS)
                 for (int c = 0; c < NCOPY; ++c) v.cnt[(t + 1) & 1][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
         }
-        // the children of this workgroup are consecutive, hence their segments form a range
-        // [b_lo, b_hi] (usually 1-3 segments): find it once (uniform search), then every child
-        // searches only inside it.  child j belongs to the first segment b with off[b] > j.
-        const unsigned int jfirst = (unsigned int)seg0;
-        const int64_t jl = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - 1;
-        const unsigned int jlast = jl > seg0 ? (unsigned int)jl : jfirst;
-        int b_lo = 0, b_hi = 0;
-        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
-            b_lo += (L.off[b_lo + s - 1] <= jfirst) ? s : 0;
-            b_hi += (L.off[b_hi + s - 1] <= jlast) ? s : 0;
-        }
-        b_lo = b_lo < v.nseg ? b_lo : v.nseg - 1;
-        b_hi = b_hi < v.nseg ? b_hi : v.nseg - 1;
+        int b_lo = rng[0], b_hi = rng[1];
         b_hi = b_hi < b_lo ? b_lo : b_hi;
         int w0 = 1;
         while (w0 < b_hi - b_lo + 1) w0 <<= 1;
-        // (3) issue the loads of the first NSTAGE segments of the range (16 B per lane, coalesced);
-        //     they land in LDS after the normals have been computed
         Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
-        const int nst = (b_hi - b_lo + 1) < NSTAGE ? (b_hi - b_lo + 1) : NSTAGE;
+        // the staged window: the speculative one if it covers the range, else (re)load from b_lo -
+        // 16 B per lane, coalesced; the data lands in LDS after the normals have been computed
+        const bool spec_ok = SPEC && b_lo >= spec_lo && b_hi < spec_lo + NSTAGE;
+        int st_lo = spec_lo;
+        if (!spec_ok) {   // workgroup-uniform
+            st_lo = b_lo;
+            const int nst = (b_hi - b_lo + 1) < NSTAGE ? (b_hi - b_lo + 1) : NSTAGE;
 #pragma unroll
-        for (int sg = 0; sg < NSTAGE; ++sg) {
+            for (int sg = 0; sg < NSTAGE; ++sg) {
 #pragma unroll
-            for (int k = 0; k < NP; ++k) stg[sg][k] = ulonglong2{0, 0};
-            if (sg < nst) {   // workgroup-uniform: only the segments of the range cost memory traffic
-                const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)(b_lo + sg) * SEG);
+                for (int k = 0; k < NP; ++k) stg[sg][k] = ulonglong2{0, 0};
+                if (sg < nst) {   // only the segments of the range cost memory traffic
+                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)(b_lo + sg) * SEG);
 #pragma unroll
-                for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
+                    for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
+                }
             }
         }
-        blo = b_lo;
+        blo = st_lo;
         int pos[NQ];
         unsigned int jj[NQ];
 #pragma unroll
