@@ -121,6 +121,15 @@ int smc_kalman_log_likelihood(const double* raw, int64_t n_theta, const double* 
  * (README.md:41,51 summaries; src/plotting_utils.jl:116-124 estimated_trend). mean, var: [d][n_theta]. */
 int smc_get_moments(smc_handle h, double* mean, double* var);
 
+/* weighted quantiles of state coordinate `component` under the current weights, per filter, on the
+ * device: what quantile(smc.x[i], weights(smc.w[i]), [0.25,0.5,0.75]) computes per theta-particle in
+ * examples/inflation_example.jl:45-46 (and README.md:41,51 for an unweighted cloud).  Definition: the
+ * inverse of the weighted empirical CDF in the filter's integer weights - the smallest particle value v
+ * with sum{W_i : x_i <= v} > floor(p * sum W) - no interpolation between particles (StatsBase
+ * interpolates; it is not vendored, so that variant is unpinned).  np <= 8; out [n_theta][np];
+ * NaN for a collapsed filter. */
+int smc_get_quantiles(smc_handle h, int component, const double* p, int np, double* out);
+
 /* ---- host-side helpers (no GPU needed) ---------------------------------------------------------*/
 /* simulate(rng, model, T) -> (x, y)                         src/state_space_models.jl:11-26 */
 int smc_simulate(int model_id, const double* raw, int64_t T, uint64_t seed, double* x /*[d][T]*/, double* y /*[T]*/);

@@ -74,6 +74,8 @@ def lib():
         L.orc_kalman_log_likelihood.restype = None
         L.orc_filter_moments.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_filter_moments.restype = None
+        L.orc_filter_quantiles.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
+        L.orc_filter_quantiles.restype = C.c_int
         L.orc_log_likelihood_batch.argtypes = [C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_uint64,
                                                C.c_uint32, _dp, C.c_int, _dp]
         _lib = L
@@ -219,6 +221,13 @@ class Filter:
         m, v = np.zeros(self.d), np.zeros(self.d)
         lib().orc_filter_moments(self._h, _d(m), _d(v))
         return m, v
+
+    def quantiles(self, p, component=0):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        out = np.zeros(p.size)
+        if lib().orc_filter_quantiles(self._h, int(component), _d(p), p.size, _d(out)) != 0:
+            raise ValueError("bad component")
+        return out
 
     def weights_raw(self):
         ns = self.nseg

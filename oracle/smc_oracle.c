@@ -761,6 +761,55 @@ void orc_kalman_log_likelihood(const double* raw, const double* y, int64_t T, in
     out[0] = x; out[1] = S; out[2] = logZ;
 }
 
+/* Weighted quantiles of state coordinate `comp` under the current weights: what
+ * quantile(smc.x[i], weights(smc.w[i]), p) delivers per theta-particle in examples/inflation_example.jl:45
+ * (StatsBase.jl, not vendored).  Definition used here (integer, order-free): with W_i = q_i >> sh_b the
+ * weight of particle i in the units of the combined segment table and Wtot = sum W_i,
+ *     quantile(p) = the smallest particle value v with  sum{W_i : x_i <= v} > floor(p * Wtot)
+ * i.e. the inverse of the weighted empirical CDF (no interpolation between particles; values are
+ * ordered by the IEEE total order of their bits, so -0.0 < +0.0).  NaN if every weight is 0.
+ * This oracle SORTS; the device does a radix select - two different algorithms for the same definition. */
+typedef struct { uint64_t key, w; } orc_kw;
+static int kw_cmp(const void* a, const void* b) {
+    uint64_t x = ((const orc_kw*)a)->key, y = ((const orc_kw*)b)->key;
+    return x < y ? -1 : x > y;
+}
+static uint64_t order_key(double v) { uint64_t b = d2bits(v); return (b >> 63) ? ~b : (b | 0x8000000000000000ULL); }
+static double key_value(uint64_t k) { return bits2d((k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k); }
+uint64_t orc_prob_to_u64(double p) {   /* floor(p * 2^64), clamped to [0, 2^64-1] */
+    if (!(p > 0.0)) return 0;
+    if (p >= 1.0) return ~(uint64_t)0;
+    return (uint64_t)(p * 0x1p64);
+}
+int orc_filter_quantiles(const orc_filter* f, int comp, const double* p, int np, double* out) {
+    const orc_weights* W = &f->W;
+    if (comp < 0 || comp >= f->model.d || np < 1) return -1;
+    const int64_t n = f->n;
+    orc_kw* kw = (orc_kw*)malloc(sizeof(orc_kw) * (size_t)n);
+    uint64_t tot = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int b = (int)(i / W->seg), j = (int)(i % W->seg);
+        const double dk = W->K - W->kb[b];
+        int sh = (dk >= 0.0 && dk < 64.0) ? (int)dk + W->SH : 64;
+        if (sh > 64) sh = 64;
+        const uint64_t q = W->C[i] - (j ? W->C[i - 1] : 0);
+        kw[i].key = order_key(f->x[(size_t)comp * n + i]);
+        kw[i].w = sh < 64 ? q >> sh : 0;
+        tot += kw[i].w;
+    }
+    qsort(kw, (size_t)n, sizeof(orc_kw), kw_cmp);
+    for (int k = 0; k < np; ++k) {
+        if (!tot) { out[k] = bits2d(0x7ff8000000000000ULL); continue; }
+        const uint64_t T = (uint64_t)(((u128)orc_prob_to_u64(p[k]) * tot) >> 64);
+        uint64_t run = 0;
+        int64_t i = 0;
+        for (; i < n; ++i) { run += kw[i].w; if (run > T) break; }
+        out[k] = key_value(kw[i < n ? i : n - 1].key);
+    }
+    free(kw);
+    return 0;
+}
+
 /* weighted mean and variance of every state coordinate under the current weights (plain sums) */
 void orc_filter_moments(const orc_filter* f, double* mean, double* var) {
     const int64_t n = f->n;

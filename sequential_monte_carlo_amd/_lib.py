@@ -18,7 +18,7 @@ FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
 EXPORTS = [
     "smc_create", "smc_destroy", "smc_set_params", "smc_set_streams", "smc_reseed", "smc_init", "smc_step",
     "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_copy_from", "smc_slot_bytes", "smc_pack_slots", "smc_unpack_slots", "smc_get_weights_raw", "smc_get_geometry",
-    "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_event_overhead_ms", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_simulate", "smc_model_dim",
+    "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_event_overhead_ms", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_get_quantiles", "smc_simulate", "smc_model_dim",
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
     "smc_host_box_muller", "smc_device_math", "smc_last_error", "smc_version",
 ]
@@ -93,6 +93,7 @@ def lib():
     L.smc_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, _i32p, C.c_int]
     L.smc_kalman_log_likelihood.argtypes = [_dp, C.c_int64, _dp, C.c_int64, C.c_int, _dp, C.c_int]
     L.smc_get_moments.argtypes = [h, _dp, _dp]
+    L.smc_get_quantiles.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
     L.smc_simulate.argtypes = [C.c_int, _dp, C.c_int64, C.c_uint64, _dp, _dp]
     L.smc_model_dim.argtypes = [C.c_int]
     L.smc_model_nraw.argtypes = [C.c_int]
@@ -252,6 +253,13 @@ class Handle:
         v = np.zeros((self.d, self.n_theta))
         check(lib().smc_get_moments(self._h, _d(m), _d(v)))
         return m, v
+
+    def quantiles(self, p, component=0):
+        """weighted quantiles of one state coordinate under the current weights, [n_theta][len(p)], on the device."""
+        p = np.ascontiguousarray(p, dtype=np.float64).ravel()
+        out = np.zeros((self.n_theta, p.size))
+        check(lib().smc_get_quantiles(self._h, int(component), _d(p), p.size, _d(out)))
+        return out
 
     def copy_from(self, src, mask):
         m = np.ascontiguousarray(mask, dtype=np.uint8)

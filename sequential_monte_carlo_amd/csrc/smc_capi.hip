@@ -794,6 +794,41 @@ extern "C" int smc_get_moments(smc_handle h, double* mean, double* var) {
     return SMC_OK;
 }
 
+extern "C" int smc_get_quantiles(smc_handle h, int component, const double* p, int np, double* out) {
+    if (!h || !p || !out) return fail(SMC_EINVAL, "smc_get_quantiles: NULL argument");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_get_quantiles: filter not initialised");
+    if (component < 0 || component >= h->d) return fail(SMC_EINVAL, "smc_get_quantiles: component out of range");
+    if (np < 1 || np > QMAX) return fail(SMC_EINVAL, "smc_get_quantiles: 1 <= np <= 8");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    const size_t nth = (size_t)h->v.ntheta, nst = nth * np;
+    // scratch: hist [ntheta][np][256] u64 | state [ntheta][np] | P64 [np] | out [ntheta][np]
+    const size_t words = nst * 256 + nst * 3 + QMAX + nst;
+    uint64_t* buf = nullptr;
+    HIPCHK(hipMalloc((void**)&buf, words * 8));
+    unsigned long long* hist = (unsigned long long*)buf;
+    QState* st = (QState*)(buf + nst * 256);
+    uint64_t* P64 = buf + nst * 256 + nst * 3;
+    double* d_out = (double*)(P64 + QMAX);
+    uint64_t hp[QMAX];
+    for (int j = 0; j < QMAX; ++j) hp[j] = j < np ? prob_to_u64(p[j]) : 0;
+    hipError_t e = hipMemsetAsync(buf, 0, (nst * 256 + nst * 3) * 8, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(P64, hp, sizeof hp, hipMemcpyHostToDevice, h->stream);
+    int nwg = (int)((h->v.n + 4095) / 4096);
+    nwg = nwg > 256 ? 256 : nwg;
+    for (int pass = 0; pass < 8 && e == hipSuccess; ++pass) {
+        hipLaunchKernelGGL((k_qhist<256>), dim3(nwg, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, component, pass, np, st, hist);
+        hipLaunchKernelGGL(k_qselect, dim3(np, h->v.ntheta), dim3(256), 0, h->stream, pass, np, P64, st, hist, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, nst * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(SMC_EHIP, hipGetErrorString(e));
+    return SMC_OK;
+}
+
 // ---- host-side helpers ---------------------------------------------------------------------------
 template <int MODEL>
 static void simulate_t(const Params& p, int64_t T, uint64_t seed, double* x, double* y) {

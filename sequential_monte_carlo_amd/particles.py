@@ -88,6 +88,13 @@ class Particles:
             m, v = m[..., 0], v[..., 0]
         return (m[0], v[0]) if self._f.single else (m, v)
 
+    def quantile(self, p, component=0):
+        """Weighted quantiles of the filtered state (`quantile(x, weights(w), p)`,
+        examples/inflation_example.jl:45), computed on the device: the inverse of the weighted
+        empirical CDF (no interpolation between particles).  [len(p)] or [n_theta][len(p)]."""
+        q = self._f.h.quantiles(p, component)
+        return q[0] if self._f.single else q
+
     def ancestors(self):
         _, _, a = self._f.h.state(want_w=False, want_anc=True)
         return a[0] if self._f.single else a

@@ -133,6 +133,40 @@ def test_moments_on_device(ob):
     assert np.allclose(mu, np.einsum("tn,tnd->td", np.asarray(wu), np.asarray(xu)), rtol=1e-12)
 
 
+def test_quantiles_on_device(ob):
+    """smc_get_quantiles (radix select on the device) == the oracle's sort-based weighted quantiles,
+    bit for bit, for single- and multi-segment filters, every state coordinate, and a collapsed filter."""
+    from sequential_monte_carlo_amd import _lib as L
+    ps = [0.0, 0.01, 0.25, 0.5, 0.75, 0.999, 1.0]
+    LGR, SVR, UCR = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0], [-1.0, 0.95, 0.25], [0.2, 0.2, 3.0, 0.0, 0.0]
+    for model, raw, n, seg, nth in ((1, LGR, 1024, 0, 3), (1, LGR, 5000, 1024, 2), (3, UCR, 3000, 512, 2), (2, SVR, 70000, 2048, 1)):
+        _, y = ob.simulate(model, raw, 9, 5)
+        h = L.Handle(model, nth, n, seg=seg, seed=17)
+        h.set_params(np.tile(raw, (nth, 1)))
+        h.log_likelihood(y)
+        for c in range(h.d):
+            q = h.quantiles(ps, c)
+            assert q.shape == (nth, len(ps)) and np.all(np.diff(q, axis=1) >= 0)
+            for th in range(nth):
+                f = ob.Filter(model, raw, n, seg=seg, seed=17, stream=th)
+                f.log_likelihood(y)
+                assert np.array_equal(q[th].view(np.uint64), f.quantiles(ps, c).view(np.uint64)), (model, n, seg, c, th)
+        # the median sits inside the central mass of the weighted cloud
+        x, w, _ = h.state(want_anc=False)
+        o = np.argsort(x[0, 0]); cw = np.cumsum(w[0][o])
+        med = h.quantiles([0.5])[0, 0]
+        assert x[0, 0][o][np.searchsorted(cw, 0.499)] <= med <= x[0, 0][o][min(np.searchsorted(cw, 0.501), n - 1)]
+        h.close()
+    # collapsed filter (every log-weight -inf): NaN
+    h = L.Handle(2, 1, 512, seed=1)
+    h.set_params(SVR)
+    h.init(1e200)
+    assert np.all(np.isnan(h.quantiles([0.5])))
+    with pytest.raises(L.SmcError):
+        h.quantiles([0.5], component=1)
+    h.close()
+
+
 def test_pack_unpack_slots_roundtrip():
     """smc_pack_slots / smc_unpack_slots through a torch device buffer (what the RCCL all-to-all moves)."""
     import torch
