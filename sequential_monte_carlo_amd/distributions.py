@@ -14,6 +14,9 @@ class Normal:
     def rand(self, rng):
         return self.mu + self.sigma * rng.standard_normal()
 
+    def rand_v(self, rng, m):
+        return self.mu + self.sigma * rng.standard_normal(m)
+
     def logpdf(self, x):
         z = (x - self.mu) / self.sigma
         return -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma)
@@ -41,6 +44,10 @@ class TruncatedNormal:
         u = self._a + (self._b - self._a) * rng.random()
         return min(max(self.mu + self.sigma * float(ndtri(u)), self.lo), self.hi)
 
+    def rand_v(self, rng, m):
+        u = self._a + (self._b - self._a) * rng.random(m)
+        return np.clip(self.mu + self.sigma * ndtri(u), self.lo, self.hi)
+
     def logpdf(self, x):
         if not self.insupport(x):
             return -math.inf
@@ -65,6 +72,9 @@ class LogNormal:
 
     def rand(self, rng):
         return math.exp(self.mu + self.sigma * rng.standard_normal())
+
+    def rand_v(self, rng, m):
+        return np.exp(self.mu + self.sigma * rng.standard_normal(m))
 
     def logpdf(self, x):
         if x <= 0:
@@ -91,6 +101,9 @@ class Uniform:
 
     def rand(self, rng):
         return self.lo + (self.hi - self.lo) * rng.random()
+
+    def rand_v(self, rng, m):
+        return self.lo + (self.hi - self.lo) * rng.random(m)
 
     def logpdf(self, x):
         return -math.log(self.hi - self.lo) if self.insupport(x) else -math.inf
@@ -135,6 +148,13 @@ class Product:
 
     def rand(self, rng):
         return np.array([p.rand(rng) for p in self.parts])
+
+    def rand_many(self, rng, m):
+        """m draws at once, [m, d]; component by component (each component vectorised when it can be)"""
+        cols = []
+        for p in self.parts:
+            cols.append(p.rand_v(rng, m) if hasattr(p, "rand_v") else np.array([p.rand(rng) for _ in range(m)]))
+        return np.column_stack(cols)
 
     def logpdf(self, theta):
         return float(sum(p.logpdf(float(t)) for p, t in zip(self.parts, theta)))

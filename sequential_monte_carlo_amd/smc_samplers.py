@@ -81,7 +81,10 @@ class SMC:
         self.raw_fn = raw_fn
         self.rng = np.random.default_rng(seed)
         self.seed = int(seed)
-        self.theta = np.array([np.atleast_1d(prior.rand(self.rng)) for _ in range(self.M)], dtype=np.float64)
+        if hasattr(prior, "rand_many"):
+            self.theta = np.ascontiguousarray(prior.rand_many(self.rng, self.M), dtype=np.float64)
+        else:
+            self.theta = np.array([np.atleast_1d(prior.rand(self.rng)) for _ in range(self.M)], dtype=np.float64)
         self.omega = np.full(self.M, 1.0 / self.M)
         self.logZ = np.zeros(self.M)
         self.ess = float(self.M)
@@ -167,7 +170,17 @@ def random_walk_kernel(theta):
     else:
         sigma = (2.83 ** 2 / d) * cov + 1e-10 * np.eye(d)
     L = np.linalg.cholesky(sigma)
-    return lambda x, scale, rng: x + math.sqrt(scale) * (L @ rng.standard_normal(d))   # MvNormal(x, scale*Sigma)
+
+    def kernel(x, scale, rng):                       # MvNormal(x, scale*Sigma)
+        return x + math.sqrt(scale) * (L @ rng.standard_normal(d))
+
+    def many(theta, scale, rng):
+        """one proposal per row of theta: the same normals, in the same order, as M calls of kernel()"""
+        z = rng.standard_normal((theta.shape[0], d))
+        return theta + math.sqrt(scale) * (z @ L.T)
+
+    kernel.many = many
+    return kernel
 
 
 def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
@@ -180,7 +193,7 @@ def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
         out.write("\t[rejuvenating]")
     many = hasattr(smc.prior, "logpdf_many")
     for c in range(smc.chain):
-        prop = np.array([kernel(smc.theta[m], scales[c], smc.rng) for m in range(smc.M)])
+        prop = kernel.many(smc.theta, scales[c], smc.rng)      # all M proposals of this chain position
         u = smc.rng.random(smc.M)
         if many:
             ok = smc.prior.insupport_many(prop)
