@@ -78,7 +78,10 @@ static hipError_t resident_t(const FilterView& v, int T, StepRec* recs, hipStrea
 template <>
 hipError_t launch_resident<SMC_MODEL>(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
     const char* e = getenv("SMC_RES_NP");   // tuning knob
-    const int np = e ? atoi(e) : 0;
+    // measured (scripts/res_tune.py): with few filters in flight (<= 4 waves per SIMD at two pairs per
+    // thread) the cheap LG model runs faster with one pair per thread (twice the waves); SV / UCSV and
+    // large batches prefer two pairs per thread
+    const int np = e ? atoi(e) : (SMC_MODEL == MODEL_LG1D && v.seg == 1024 && v.ntheta <= 1024) ? 1 : 0;
     switch (v.seg) {
     case 256: return resident_t<128, 1>(v, T, recs, s);
     case 512: return resident_t<256, 1>(v, T, recs, s);
