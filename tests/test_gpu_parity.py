@@ -343,6 +343,24 @@ def test_uneven_weights_far_segments(L, ob):
         h.close()
 
 
+def test_many_segments_per_thread_bit_exact(L, ob):
+    """More segments than threads in a workgroup (several table entries per thread in the segment-table
+    and offsets prologues): 586 and 1172 segments of 256, and 700 segments of 2048; still bit-exact."""
+    for model, raw, n, seg, T in ((1, LG, 150000, 256, 4), (2, SV, 300000, 256, 3), (1, LG, 700 * 2048 - 77, 2048, 3)):
+        _, y = ob.simulate(model, raw, T, 3)
+        h = L.Handle(model, 1, n, seg=seg, seed=5, flags=L.FLAG_ANCESTORS)
+        h.set_params(raw)
+        logZ, lm, es = h.log_likelihood(y, trace=True)
+        x, w, a = h.state()
+        f = ob.Filter(model, raw, n, seg=seg, seed=5)
+        z, olm, oes = f.log_likelihood(y, trace=True)
+        ox, ow, oa, _ = f.state()
+        assert bits([logZ[0]])[0] == bits([z])[0] and same(lm[:, 0], olm) and same(es[:, 0], oes), (model, n, seg)
+        assert same(x[:, 0], ox) and same(w[0], ow) and np.array_equal(a[0], oa), (model, n, seg)
+        assert np.array_equal(h.quantiles([0.1, 0.5, 0.9]).view(np.uint64)[0], f.quantiles([0.1, 0.5, 0.9]).view(np.uint64))
+        h.close()
+
+
 def test_step_api_multi_segment_with_permute_and_copy(L, ob):
     """smc_step on multi-segment filters interleaved with smc_permute / smc_copy_from."""
     _, y = ob.simulate(1, LG, 10, 1998)
