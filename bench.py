@@ -29,6 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# secondary (ALU) ceiling: 256 CUs x 4 SIMDs; measured by scripts/dbg/valu_rates.hip on this pool: 4.3-4.7 cycles
+# per wave64 f64 / 64-bit-integer VALU instruction with 4 waves per SIMD, core clock 2.2-2.4 GHz under VALU load
+N_SIMD, VALU_CYCLES_PER_INST, CLOCK_GHZ = 1024, 4.4, 2.3
 
 LG = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0]
 SV = [-1.0, 0.95, 0.25]
@@ -146,16 +149,26 @@ def main():
             units = float(nth) * nx
             kname = "k_step"
         achieved = units * bytes_per_pstep / (ms * 1e-3) / 1e9
-        traffic = None
+        traffic, valu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                prof = json.load(open(pmc))
+                traffic = prof.get("hbm_bytes_per_launch")
+                wi = prof.get("valu_wave_insts_per_launch")
+                if wi:
+                    # secondary ceiling (SURVEY 8d "FP64 vector ALU"): the launch's VALU instructions
+                    # (rocprofv3 SQ_INSTS_VALU) at the measured issue cost on 1024 SIMDs
+                    floor_ms = wi * VALU_CYCLES_PER_INST / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3
+                    valu = {"bound": "valu", "wave_insts_per_launch": round(wi), "cycles_per_inst": VALU_CYCLES_PER_INST,
+                            "clock_ghz": CLOCK_GHZ, "floor_ms": round(floor_ms, 6), "frac": round(floor_ms / ms, 4)}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "launch_ms": round(ms, 6), "algorithmic_bytes_per_launch": units * bytes_per_pstep}
+        if valu:
+            roof["secondary"] = valu       # the HBM model is SURVEY's accounting; the kernel's real ceiling is the ALU
         if not h.resident:
             roof["empty_event_bracket_ms"] = round(ovh, 6)   # rocprofv3's kernel-only average is ~2 us below launch_ms
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace smc;
@@ -293,6 +294,25 @@ extern "C" int smc_destroy(smc_handle h) {
         const char* nm[8] = {"", "offsets", "range+stage-issue+lookup", "normals", "T2+stage-write+barrier", "search", "gather+model+store", "epilogue"};
         for (int k = 1; k < 8; ++k) fprintf(stderr, " %s=%.2f", nm[k], ph[k] / nwg);
         fprintf(stderr, "\n");
+        {   // the slowest workgroups: where do they lose time, and where do they sit (XCD = launch index % 8)
+            std::vector<size_t> idx(nwg);
+            for (size_t w = 0; w < nwg; ++w) idx[w] = w;
+            std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return st[a * 8 + 7] > st[b * 8 + 7]; });
+            for (size_t r = 0; r < 6 && r < nwg; ++r) {
+                const size_t w = idx[r];
+                fprintf(stderr, "[dbg]   late #%zu wg %zu xcd %zu: start %.2f end %.2f phases", r, w, w % 8, (double)(st[w * 8] - t0) * 0.01,
+                        (double)(st[w * 8 + 7] - t0) * 0.01);
+                for (int k = 1; k < 8; ++k) fprintf(stderr, " %.2f", (double)(st[w * 8 + k] - st[w * 8 + k - 1]) * 0.01);
+                fprintf(stderr, "\n");
+            }
+            double endq[5];
+            std::vector<double> ends(nwg);
+            for (size_t w = 0; w < nwg; ++w) ends[w] = (double)(st[w * 8 + 7] - t0) * 0.01;
+            std::sort(ends.begin(), ends.end());
+            const double qs[5] = {0.1, 0.5, 0.9, 0.99, 1.0};
+            for (int k = 0; k < 5; ++k) endq[k] = ends[(size_t)((nwg - 1) * qs[k])];
+            fprintf(stderr, "[dbg]   end-time quantiles (us) 10%%=%.2f 50%%=%.2f 90%%=%.2f 99%%=%.2f max=%.2f\n", endq[0], endq[1], endq[2], endq[3], endq[4]);
+        }
         (void)hipFree(h->v.dbg);
     }
 #endif
