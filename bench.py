@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["dt"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["dt", "smc2"])
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -78,8 +78,8 @@ def main():
 
     from sequential_monte_carlo_amd import _lib as L
 
-    if args.workload == "dt":
-        return bench_density_tempered(args, rank, local_rank, world, dist, torch)
+    if args.workload in ("dt", "smc2"):
+        return bench_density_tempered(args, rank, local_rank, world, dist, torch, algo=args.workload)
     model, raw, nth, nx, T, desc = WORKLOADS[args.workload]
     _, y = L.simulate(model, raw if model != 3 else UC, T, 1998)
     if args.workload == "c5":
@@ -241,9 +241,11 @@ def julia_baseline(nx):
         return "julia failed: %s" % e
 
 
-def bench_density_tempered(args, rank, local_rank, world, dist, torch):
-    """Whole sampler: density_tempered (src/smc_samplers.jl:222-281) on the README's LG model
-    (README.md:81-98): N_theta = 512 per GPU x Nx = 1024, T = 200, chain = 3, ess_threshold = 0.5.
+def bench_density_tempered(args, rank, local_rank, world, dist, torch, algo="dt"):
+    """Whole sampler on the README's LG model (README.md:81-98): N_theta = 512 per GPU x Nx = 1024, T = 200,
+    chain = 3, ess_threshold = 0.5.  algo "dt": density_tempered (src/smc_samplers.jl:222-281);
+    "smc2": the online SMC^2 run of BASELINE configs[3] (smc2 then smc2! for t = 2..T, smc_samplers.jl:288-340;
+    PMMH rejuvenation re-filters y[1:t-1] whenever the outer ESS drops below the threshold).
     A "step" is one complete run; every executed inner particle-step is counted."""
     import io
     import sequential_monte_carlo_amd as smc
@@ -268,7 +270,16 @@ def bench_density_tempered(args, rank, local_rank, world, dist, torch):
 
     def run(seed):
         s = smc.SMC(N, M, mod, prior, chain, 0.5, seed=seed, backend=backend, comm=comm, raw_fn=raw_fn)
-        stages = smc.density_tempered(s, y, verbose=False, out=io.StringIO())
+        if algo == "dt":
+            stages = smc.density_tempered(s, y, verbose=False, out=io.StringIO())
+        else:
+            sink = io.StringIO()
+            smc.smc2(s, y)
+            stages = []
+            for t in range(2, T + 1):
+                if s.ess < s.ess_min:
+                    stages.append(t)            # a resample-move happens inside this step
+                smc.smc2_step(s, y, t, verbose=False, out=sink)
         return s, stages
 
     for k in range(args.warmup):
@@ -292,7 +303,8 @@ def bench_density_tempered(args, rank, local_rank, world, dist, torch):
             "metric": "particle-steps/sec", "value": psteps / elapsed, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "density_tempered LG (README.md:81-98) Ntheta=%d (512/GPU) x Nx=1024 T=200 chain=3" % M,
+            "config": {"workload": "%s LG (README.md:81-98) Ntheta=%d (512/GPU) x Nx=1024 T=200 chain=3"
+                                   % ("density_tempered" if algo == "dt" else "online SMC^2 (BASELINE configs[3])", M),
                        "stages_last_run": len(stages), "psteps_per_run": s.psteps, "posterior_mean": [float(v) for v in smc.expected_parameters(s)]},
             "roofline": None, "cpu_baseline": None}))
     backend.close()

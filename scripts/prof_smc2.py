@@ -1,4 +1,4 @@
-"""Host-side profile of one density_tempered run (README model, Ntheta=512 x Nx=1024, T=200, chain 3)."""
+"""Host-side profile of one online SMC^2 run (README model, Ntheta=512 x Nx=1024, T=200, chain 3)."""
 import cProfile, io, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -15,10 +15,13 @@ def raw_fn(th):
     return 1, np.column_stack([th[:, 0], np.ones(m), th[:, 1], th[:, 2], np.zeros(m), np.ones(m)])
 def run(seed):
     s = smc.SMC(N, M, mod, prior, chain, 0.5, seed=seed, backend=backend, raw_fn=raw_fn)
-    st = smc.density_tempered(s, y, verbose=False, out=io.StringIO())
-    return s, st
+    sink = io.StringIO()
+    smc.smc2(s, y)
+    for t in range(2, T + 1):
+        smc.smc2_step(s, y, t, verbose=False, out=sink)
+    return s
 run(1)
-t0 = time.perf_counter(); s, st = run(2); dt = time.perf_counter() - t0
-print("run %.2f ms, %d stages, psteps %.3e -> %.3e p-steps/s" % (dt * 1e3, len(st), s.psteps, s.psteps / dt))
+t0 = time.perf_counter(); s = run(2); dt = time.perf_counter() - t0
+print("run %.2f ms, psteps %.3e -> %.3e p-steps/s" % (dt * 1e3, s.psteps, s.psteps / dt))
 pr = cProfile.Profile(); pr.enable(); run(3); pr.disable()
-o = io.StringIO(); pstats.Stats(pr, stream=o).sort_stats("cumtime").print_stats(30); print(o.getvalue()[:4000])
+o = io.StringIO(); pstats.Stats(pr, stream=o).sort_stats("tottime").print_stats(22); print(o.getvalue()[:4500])

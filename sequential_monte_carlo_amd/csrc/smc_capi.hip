@@ -45,6 +45,7 @@ struct smc_filter_s {
     int64_t trcap = 0;
     double* d_wdense = nullptr;
     StepRec* d_recs = nullptr;
+    double* h_pin = nullptr;                   // pinned host mirror [3][ntheta]: logZ | last_logmu | last_ess
     unsigned long long* dbg_count = nullptr;   // diagnostic builds only
     int64_t reccap = 0;
     hipStream_t stream = nullptr;
@@ -243,6 +244,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     TRY(dalloc(&v.last_ess, nt));
     TRY(dalloc(&v.last_K, nt));
     TRY(dalloc(&v.last_D, nt));
+    TRY(hipHostMalloc((void**)&h->h_pin, 3 * nt * 8, hipHostMallocDefault));
     TRY(hipMemsetAsync(v.logZ, 0, nt * 8, h->stream));
     std::vector<uint32_t> st(nt);
     for (size_t m = 0; m < nt; ++m) st[m] = (uint32_t)m;
@@ -320,6 +322,7 @@ extern "C" int smc_destroy(smc_handle h) {
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]); (void)hipFree(v.cnt[b]);
     }
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
@@ -392,12 +395,21 @@ static int ensure_recs(smc_handle h, int64_t T) {
     return SMC_OK;
 }
 
-static int finish_timing(smc_handle h) {
+// Close the timed region (ev1), then bring the requested per-filter result vectors to the host through
+// the pinned mirror: asynchronous copies queued behind the kernels, ONE stream synchronisation for all.
+static int finish_timing(smc_handle h, double* logZ = nullptr, double* logmu = nullptr, double* ess = nullptr) {
+    const size_t nt = (size_t)h->v.ntheta;
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipEventSynchronize(h->ev1));
+    if (logZ) HIPCHK(hipMemcpyAsync(h->h_pin, h->v.logZ, nt * 8, hipMemcpyDeviceToHost, h->stream));
+    if (logmu) HIPCHK(hipMemcpyAsync(h->h_pin + nt, h->v.last_logmu, nt * 8, hipMemcpyDeviceToHost, h->stream));
+    if (ess) HIPCHK(hipMemcpyAsync(h->h_pin + 2 * nt, h->v.last_ess, nt * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_ms = ms;
+    if (logZ) memcpy(logZ, h->h_pin, nt * 8);
+    if (logmu) memcpy(logmu, h->h_pin + nt, nt * 8);
+    if (ess) memcpy(ess, h->h_pin + 2 * nt, nt * 8);
     return SMC_OK;
 }
 
@@ -421,10 +433,7 @@ extern "C" int smc_init(smc_handle h, double y1, double* logmu) {
     h->t = 1; h->inited = true; h->emitted = false;
     int rc = emit_if_needed(h);
     if (rc) return rc;
-    rc = finish_timing(h);
-    if (rc) return rc;
-    if (logmu) HIPCHK(hipMemcpy(logmu, h->v.last_logmu, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
-    return SMC_OK;
+    return finish_timing(h, nullptr, logmu, nullptr);
 }
 
 // bootstrap_filter!(x, w, y, model)   particles.jl:107-129
@@ -439,11 +448,7 @@ extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
     h->cur ^= 1; h->t += 1; h->emitted = false;
     int rc = emit_if_needed(h);
     if (rc) return rc;
-    rc = finish_timing(h);
-    if (rc) return rc;
-    if (logmu) HIPCHK(hipMemcpy(logmu, h->v.last_logmu, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
-    if (ess) HIPCHK(hipMemcpy(ess, h->v.last_ess, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
-    return SMC_OK;
+    return finish_timing(h, nullptr, logmu, ess);
 }
 
 // log_likelihood(N, y, model)   particles.jl:132-147
@@ -483,10 +488,9 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
         if (rc) return rc;
     }
     h->v.want_s2 = 1;
-    rc = finish_timing(h);
+    rc = finish_timing(h, logZ);
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     if (rc) return rc;
-    if (logZ) HIPCHK(hipMemcpy(logZ, h->v.logZ, (size_t)h->v.ntheta * 8, hipMemcpyDeviceToHost));
     if (logmu_trace) HIPCHK(hipMemcpy(logmu_trace, h->d_tr_logmu, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
     if (ess_trace) HIPCHK(hipMemcpy(ess_trace, h->d_tr_ess, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
     return SMC_OK;

@@ -96,6 +96,7 @@ class SMC:
         self._calls = 0          # evaluation counter -> fresh Philox seed per batched evaluation
         self.psteps = 0          # executed inner particle-steps (all ranks), SURVEY 8(d)
         self._main = None        # device handle of the online filters (smc2)
+        self._theta_dev = None   # (handle, theta slice) whose parameter rows are on the device
         self.t = 0
 
     # -- batched inner filters --------------------------------------------------------------------
@@ -278,7 +279,11 @@ def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
         rejuvenate_(smc, y[: t - 1], 1.0, verbose, out)
         _exchange(smc, y[: t - 1], verbose, out)
     logw = np.log(smc.omega)
-    smc._main.set_params(_rows(smc._models(smc.theta[smc.lo:smc.hi]))[1])
+    th_loc = smc.theta[smc.lo:smc.hi]
+    if smc._theta_dev is None or smc._theta_dev[0] is not smc._main or not np.array_equal(smc._theta_dev[1], th_loc):
+        # the parameter rows on the device follow theta (resample!/rejuvenate! change it); unchanged -> no upload
+        smc._main.set_params(_rows(smc._models(th_loc))[1])
+        smc._theta_dev = (smc._main, th_loc.copy())
     lik, _ = smc._main.step(float(y[t - 1]))
     lik = smc._gather(np.asarray(lik, dtype=np.float64))
     smc.psteps += smc.M * smc.N
