@@ -244,7 +244,8 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     TRY(dalloc(&v.last_ess, nt));
     TRY(dalloc(&v.last_K, nt));
     TRY(dalloc(&v.last_D, nt));
-    TRY(hipHostMalloc((void**)&h->h_pin, 3 * nt * 8, hipHostMallocDefault));
+    TRY(hipHostMalloc((void**)&h->h_pin, 3 * nt * 8, hipHostMallocDefault));   // coherent, device-visible
+    v.host_out = h->h_pin;
     TRY(hipMemsetAsync(v.logZ, 0, nt * 8, h->stream));
     std::vector<uint32_t> st(nt);
     for (size_t m = 0; m < nt; ++m) st[m] = (uint32_t)m;
@@ -395,15 +396,12 @@ static int ensure_recs(smc_handle h, int64_t T) {
     return SMC_OK;
 }
 
-// Close the timed region (ev1), then bring the requested per-filter result vectors to the host through
-// the pinned mirror: asynchronous copies queued behind the kernels, ONE stream synchronisation for all.
+// Close the timed region (ev1) and hand the requested per-filter result vectors to the caller from the
+// pinned mirror (FilterView::host_out): ONE stream synchronisation, no copy commands.
 static int finish_timing(smc_handle h, double* logZ = nullptr, double* logmu = nullptr, double* ess = nullptr) {
     const size_t nt = (size_t)h->v.ntheta;
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    if (logZ) HIPCHK(hipMemcpyAsync(h->h_pin, h->v.logZ, nt * 8, hipMemcpyDeviceToHost, h->stream));
-    if (logmu) HIPCHK(hipMemcpyAsync(h->h_pin + nt, h->v.last_logmu, nt * 8, hipMemcpyDeviceToHost, h->stream));
-    if (ess) HIPCHK(hipMemcpyAsync(h->h_pin + 2 * nt, h->v.last_ess, nt * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // the emitting kernel stored the results in the pinned mirror itself
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_ms = ms;
@@ -429,8 +427,12 @@ extern "C" int smc_init(smc_handle h, double y1, double* logmu) {
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     h->cur = 0;
-    HIPCHK(do_init(h, y1));
-    h->t = 1; h->inited = true; h->emitted = false;
+    const bool own = h->v.nseg == 1;   // one workgroup owns the filter: it emits (logmu, ess) itself
+    h->v.emit_now = own ? 1 : 0;
+    hipError_t le = do_init(h, y1);
+    h->v.emit_now = 0;
+    HIPCHK(le);
+    h->t = 1; h->inited = true; h->emitted = own;
     int rc = emit_if_needed(h);
     if (rc) return rc;
     return finish_timing(h, nullptr, logmu, nullptr);
@@ -444,8 +446,12 @@ extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     HIPCHK(do_count(h, h->t, h->emitted ? 0 : 1));
-    HIPCHK(do_step(h, h->t, h->emitted ? 0 : 1, y_t));
-    h->cur ^= 1; h->t += 1; h->emitted = false;
+    const bool own = h->v.nseg == 1;
+    h->v.emit_now = own ? 1 : 0;
+    hipError_t le = do_step(h, h->t, h->emitted ? 0 : 1, y_t);
+    h->v.emit_now = 0;
+    HIPCHK(le);
+    h->cur ^= 1; h->t += 1; h->emitted = own;
     int rc = emit_if_needed(h);
     if (rc) return rc;
     return finish_timing(h, nullptr, logmu, ess);

@@ -65,6 +65,10 @@ struct FilterView {
     double* trace_logmu;     // [T][ntheta] or nullptr
     double* trace_ess;       // [T][ntheta] or nullptr
     const double* y;         // [T] on device (log_likelihood) or nullptr
+    double* host_out;        // pinned host mirror [3][ntheta] of (logZ | last_logmu | last_ess): whoever emits
+                             //    these also stores them here, so the host needs no copy after its stream sync
+    int emit_now;            // single-segment step API: the launch emits (logmu, ess) of ITS OWN weights at the end
+                             //    (one workgroup owns the whole filter), so no finalize launch follows
     int want_s2;             // 1: accumulate sum q^2 (ESS) in this launch; 0: its consumer never reads it
                              //    (log_likelihood discards ess, particles.jl:142: only the last step / traces need it)
     int abl;                 // ablation mask: always 0 in the product (profiling builds only, -DSMC_ABLATE)
@@ -330,7 +334,13 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
         v.last_D[th] = Dtot;
         if (v.trace_logmu) v.trace_logmu[(size_t)t_emit * v.ntheta + th] = logmu;
         if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
-        v.logZ[th] = first_emit ? logmu : v.logZ[th] + logmu;
+        const double z = first_emit ? logmu : v.logZ[th] + logmu;
+        v.logZ[th] = z;
+        if (v.host_out) {
+            v.host_out[th] = z;
+            v.host_out[(size_t)v.ntheta + th] = logmu;
+            v.host_out[2 * (size_t)v.ntheta + th] = ess;
+        }
     }
     __syncthreads();
     return Dtot;
@@ -434,8 +444,8 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
 
 // normalize() of one segment into the global ping-pong buffers
 template <int THREADS, int NP>
-__device__ __forceinline__ void segment_epilogue(const FilterView& v, int nxt, int th, int sb, double (&lw)[NP][2],
-                                                 uint64_t* scr) {
+__device__ __forceinline__ SegRec segment_epilogue(const FilterView& v, int nxt, int th, int sb, double (&lw)[NP][2],
+                                                   uint64_t* scr) {
     uint64_t* Cout = v.C[nxt] + (size_t)th * v.npad + (size_t)sb * v.seg;
     const SegRec rec = segment_normalize<THREADS, NP>(lw, scr, Cout, v.want_s2 != 0);
     if (threadIdx.x == 0) {
@@ -444,6 +454,29 @@ __device__ __forceinline__ void segment_epilogue(const FilterView& v, int nxt, i
         v.segS[nxt][r] = rec.S;
         v.segS2hi[nxt][r] = rec.hi;
         v.segS2lo[nxt][r] = rec.lo;
+    }
+    return rec;
+}
+
+// (logmu, ess) of a single-segment filter from its own record: exactly what table_prologue's emit
+// computes for a one-entry table (K = kb).  Thread 0 only.
+__device__ __forceinline__ void emit_own(const FilterView& v, int th, const SegRec& rec, uint32_t t_emit, bool first_emit) {
+    const int sh = seg_shift(rec.kb, rec.kb, v.SH);
+    const uint64_t D = seg_Q(rec.S, sh), R = seg_R(rec.hi, rec.lo, sh, v.SH);
+    double logmu, ess;
+    combine_outputs(rec.kb, D, R, v.SH, v.n, logmu, ess);
+    v.last_logmu[th] = logmu;
+    v.last_ess[th] = ess;
+    v.last_K[th] = rec.kb;
+    v.last_D[th] = D;
+    if (v.trace_logmu) v.trace_logmu[(size_t)t_emit * v.ntheta + th] = logmu;
+    if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
+    const double z = first_emit ? logmu : v.logZ[th] + logmu;
+    v.logZ[th] = z;
+    if (v.host_out) {
+        v.host_out[th] = z;
+        v.host_out[(size_t)v.ntheta + th] = logmu;
+        v.host_out[2 * (size_t)v.ntheta + th] = ess;
     }
 }
 
@@ -509,7 +542,8 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
                 v.cnt[1][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
             }
     }
-    segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
+    const SegRec rec = segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
+    if (v.emit_now && v.nseg == 1 && tid == 0) emit_own(v, th, rec, 0u, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -959,7 +993,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         if (acc == 1.2345) v.logZ[th] = acc;
         return;
     }
-    segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
+    const SegRec rec = segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
+    if (!MULTI && v.emit_now && tid == 0) emit_own(v, th, rec, t, false);
     SMC_STAMP(v, 7);
 }
 

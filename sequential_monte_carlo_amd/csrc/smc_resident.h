@@ -147,6 +147,10 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         if (t == T - 1) {
             v.last_logmu[th] = logmu;
             v.last_ess[th] = ess;
+            if (v.host_out) {
+                v.host_out[(size_t)v.ntheta + th] = logmu;
+                v.host_out[2 * (size_t)v.ntheta + th] = ess;
+            }
             v.last_K[th] = o.kb;
             v.last_D[th] = Qb;
             v.segk[0][th] = o.kb;
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
             z = t == 0 ? l : z + l;
         }
         v.logZ[th] = z;
+        if (v.host_out) v.host_out[th] = z;
     }
 }
 
