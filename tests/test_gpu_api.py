@@ -32,6 +32,12 @@ def test_readme_filter_loop(ob):
         assert (logmu, ess) == (olm, oess)
         xq.append(np.quantile(np.asarray(x), [0.25, 0.5, 0.75]))
         logZ += logmu
+        if t % 13 == 0:        # the same summaries on the device, under the weights (no D2H of the cloud)
+            qd = x.quantile([0.25, 0.5, 0.75])
+            assert np.array_equal(bits(qd), bits(f.quantiles([0.25, 0.5, 0.75])))
+            mean, var = x.moments()
+            xs, ws = np.asarray(x), np.asarray(w)
+            assert mean == pytest.approx(float(np.sum(ws * xs)), rel=1e-12) and var > 0 and qd[0] <= qd[1] <= qd[2]
     ox, ow, _, _ = f.state()
     assert np.array_equal(bits(np.asarray(x)), bits(ox[0])) and np.array_equal(bits(np.asarray(w)), bits(ow))
     x2, w2, logZ2 = smc.log_likelihood(1024, y, m, seed=11)
