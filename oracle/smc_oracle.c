@@ -567,7 +567,9 @@ typedef struct {
     orc_weights W;
 } orc_filter;
 
-int orc_auto_seg(int64_t n) {
+int orc_auto_seg(int64_t n) {   /* the same rule as smc_auto_seg (the segment length is part of the spec) */
+    if (n > ((int64_t)1 << 24)) return 8192;
+    if (n > ((int64_t)1 << 21)) return 4096;
     if (n > MAX_SEG) return 2048;
     int s = 256;
     while (s < n) s <<= 1;

@@ -84,6 +84,10 @@ bool geo_default(int seg, Geo& g) {
 }  // namespace smc
 
 extern "C" int smc_auto_seg(int64_t n) {
+    // measured (scripts/nx_sweep.py): 2048 up to 2^21 particles; beyond that the per-workgroup segment
+    // tables (16 B per segment in LDS) cost occupancy and 4096 wins; 8192 keeps nseg <= 4096 up to 2^25
+    if (n > ((int64_t)1 << 24)) return 8192;
+    if (n > ((int64_t)1 << 21)) return 4096;
     if (n > MAX_SEG) return 2048;
     int s = 256;
     while (s < n) s <<= 1;
