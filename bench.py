@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["dt", "smc2"])
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resampler", default="multinomial", choices=["multinomial", "systematic"],
+                    help="multinomial = the reference's resample (default, the judged configuration); systematic = opt-in "
+                         "variant (SMC_FLAG_SYSTEMATIC), reported in config.resampler")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box")
     args = ap.parse_args()
@@ -89,7 +92,8 @@ def main():
     else:
         raws = np.tile(raw, (nth, 1))
     on_gpu = dist is not None and args.dist_backend == "nccl"
-    h = L.Handle(model, nth, nx, seg=args.seg, seed=1, device=local_rank if on_gpu else 0)
+    h = L.Handle(model, nth, nx, seg=args.seg, seed=1, device=local_rank if on_gpu else 0,
+                 flags=L.FLAG_SYSTEMATIC if args.resampler == "systematic" else 0)
     h.set_params(raws)
     h.set_streams(np.arange(nth, dtype=np.uint32) + rank * nth)      # global theta index
 
@@ -151,7 +155,7 @@ def main():
         achieved = units * bytes_per_pstep / (ms * 1e-3) / 1e9
         traffic, valu = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_%s.json" % args.workload)
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.resampler == "multinomial":
             try:
                 prof = json.load(open(pmc))
                 traffic = prof.get("hbm_bytes_per_launch")
@@ -180,7 +184,7 @@ def main():
         cpu_cores = 1
         if nth == 1:
             Ts = 96
-            f = ob.Filter(model, raw, nx, seg=h.seg, seed=1, stream=0)
+            f = ob.Filter(model, raw, nx, seg=h.seg, seed=1, stream=0, systematic=args.resampler == "systematic")
             c0 = time.perf_counter()
             f.log_likelihood(y[:Ts])
             cdt = time.perf_counter() - c0
@@ -215,7 +219,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "n_theta_per_gpu": nth, "n_x": nx, "T": T, "seg": h.seg,
-                       "resident_kernel": bool(h.resident), "sharding": "theta axis, %d filter(s) per GPU" % nth,
+                       "resident_kernel": bool(h.resident), "resampler": args.resampler,
+                       "sharding": "theta axis, %d filter(s) per GPU" % nth,
                        "logZ_rank0_theta0": float(logZ[0])},
             "device_ms_per_step": dev_ms / args.steps,
             "roofline": roof, "cpu_baseline": cpu,

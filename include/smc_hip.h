@@ -37,6 +37,11 @@ extern "C" {
 /* flags of smc_create */
 #define SMC_FLAG_ANCESTORS 1u /* keep the ancestor vector `a` of the last step (particles.jl:117)      */
 #define SMC_FLAG_NO_RESIDENT 2u /* never use the LDS-resident whole-series kernel (testing)            */
+#define SMC_FLAG_SYSTEMATIC 4u /* OPT-IN: systematic resampling instead of the reference's multinomial
+                                * resample (particles.jl:17-19 draws iid): one uniform per step, child j takes
+                                * the point (j + u)/N of the weight CDF.  Same expectation N w_i of every
+                                * particle's children, lower variance, a different law - never the default.
+                                * Multi-segment filters then need no level-1 draw (one launch per step).   */
 
 typedef struct smc_filter_s* smc_handle;
 
@@ -142,6 +147,9 @@ double smc_host_exp(double x);
 double smc_host_log(double x);
 void smc_host_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void smc_host_box_muller(const uint32_t w[4], double* z0, double* z1);
+/* systematic-resampling targets T_{j0+k} = floor(((j0+k) Dtot + mulhi64(u, Dtot)) / n), k < nk <= 8192, by the
+ * division-free evaluation of the kernels; device < 0 evaluates on the host (exactness tests) */
+int smc_sys_targets(uint64_t Dtot, uint32_t n, uint64_t u, uint64_t j0, int nk, uint64_t* out, int device);
 /* the same functions evaluated on the device for n inputs (math parity tests) */
 int smc_device_math(int which /*0 exp,1 log,2 sqrt,3 box-muller z0,4 z1,5 div a/b*/, const double* a, const double* b,
                     int64_t n, double* out, int device);

@@ -72,6 +72,8 @@ def lib():
         L.orc_filter_get_weights_raw.argtypes = [C.c_void_p, _u64p, _dp, _u64p, _u64p, _u64p]
         L.orc_kalman_log_likelihood.argtypes = [_dp, _dp, C.c_int64, C.c_int, _dp]
         L.orc_kalman_log_likelihood.restype = None
+        L.orc_filter_set_systematic.argtypes = [C.c_void_p, C.c_int]
+        L.orc_filter_set_systematic.restype = None
         L.orc_filter_moments.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_filter_moments.restype = None
         L.orc_filter_quantiles.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
@@ -154,7 +156,7 @@ def resample(w, ndraw=None, seed=0, stream=0, t=0):
 class Filter:
     """One bootstrap particle filter of the oracle (particles.jl:87-147)."""
 
-    def __init__(self, model, raw, n, seg=0, seed=1, stream=0):
+    def __init__(self, model, raw, n, seg=0, seed=1, stream=0, systematic=False):
         self.model, self.n, self.d = model, int(n), MODEL_DIM[model]
         raw = np.ascontiguousarray(raw, dtype=np.float64)
         assert raw.size == MODEL_NRAW[model]
@@ -163,6 +165,8 @@ class Filter:
             raise ValueError("orc_filter_create failed")
         self.seg = lib().orc_filter_seg(self._h)
         self.nseg = (self.n + self.seg - 1) // self.seg
+        if systematic:
+            lib().orc_filter_set_systematic(self._h, 1)
 
     def __del__(self):
         if getattr(self, "_h", None):

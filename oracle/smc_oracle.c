@@ -65,6 +65,7 @@ typedef unsigned __int128 u128;
 #define SLOT_NORMAL0 1u        /* slots 1..d : state normals                              */
 #define SLOT_OBS 8u            /* simulate(): observation noise                           */
 #define SLOT_COUNT 9u          /* segment pick of draw i (multi-segment filters only)     */
+#define SLOT_SYS 10u           /* the one uniform of a systematic resampling step (opt-in) */
 
 static const double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
 static const double LOG2PI = 0x1.d67f1c864beb5p+0;
@@ -539,6 +540,34 @@ static void weights_resample(orc_weights* W, uint64_t seed, uint32_t stream, uin
     }
 }
 
+/* OPT-IN alternative to resample(): systematic resampling (one uniform u per step; child j takes the
+ * point (j + u)/n of the weight CDF).  Not the reference's law (its resample is multinomial,
+ * particles.jl:17-19) - lower variance, same expectation E[#children of i] = n w_i - so never the
+ * default.  Exact integer definition: with the combined table (Dcum, Dtot) and v0 = mulhi64(u, Dtot),
+ *     T_j = floor((j * Dtot + v0) / n)   in [0, Dtot),  j = 0..n-1   (increasing in j)
+ * picks segment b = first with Dcum[b] > T_j, and inside it the first particle a whose cumulative
+ * weight in table units (C_a >> sh_b) exceeds T_j - Dcum[b-1].  Children come out sorted by ancestor. */
+static void weights_resample_systematic(orc_weights* W, uint64_t seed, uint32_t stream, uint32_t t, int64_t* a) {
+    const int64_t n = W->n;
+    if (W->Dtot == 0) {
+        for (int64_t i = 0; i < n; ++i) a[i] = i;
+        return;
+    }
+    uint64_t r[2];
+    resample_pair(seed, 0, stream, t, SLOT_SYS, r);
+    const uint64_t v0 = (uint64_t)(((u128)r[0] * W->Dtot) >> 64);
+    for (int64_t j = 0; j < n; ++j) {
+        const uint64_t T = (uint64_t)(((u128)(uint64_t)j * W->Dtot + v0) / (u128)(uint64_t)n);
+        const int b = (int)upper_bound_u64(W->Dcum, W->nseg, T);
+        const uint64_t T2 = T - (b ? W->Dcum[b - 1] : 0);
+        const double dk = W->K - W->kb[b];
+        int sh = (dk >= 0.0 && dk < 64.0) ? (int)dk + W->SH : 64;
+        if (sh > 64) sh = 64;
+        const uint64_t thr = sh < 64 ? ((T2 + 1) << sh) - 1 : 0;      /* (C >> sh) > T2  <=>  C > thr */
+        a[j] = (int64_t)b * W->seg + upper_bound_u64(W->C + (size_t)b * W->seg, W->seg, thr);
+    }
+}
+
 /* dense normalised weights w_i (what the reference's normalize returns as `w`) */
 static void weights_dense(const orc_weights* W, double* w) {
     double Dd = (double)W->Dtot * bits2d((uint64_t)(1023 + W->SH - 48) << 52);
@@ -565,7 +594,10 @@ typedef struct {
     double *x, *xp, *logw;  /* x is [d][n] */
     int64_t* a;
     orc_weights W;
+    int systematic;         /* 0: multinomial resampling (the reference's law); 1: opt-in systematic */
 } orc_filter;
+
+void orc_filter_set_systematic(orc_filter* f, int on) { f->systematic = on ? 1 : 0; }
 
 int orc_auto_seg(int64_t n) {   /* the same rule as smc_auto_seg (the segment length is part of the spec) */
     if (n > ((int64_t)1 << 24)) return 8192;
@@ -674,7 +706,8 @@ double orc_bootstrap_filter_step(orc_filter* f, double y, double* ess) {
     const int d = f->model.d;
     const int64_t n = f->n;
     double z[3], xpi[3], xi[3], zp[3][2];
-    weights_resample(&f->W, f->seed, f->stream, f->t, f->a);    /* a = resample(weights)            */
+    if (f->systematic) weights_resample_systematic(&f->W, f->seed, f->stream, f->t, f->a);
+    else weights_resample(&f->W, f->seed, f->stream, f->t, f->a);    /* a = resample(weights)            */
     for (int k = 0; k < d; ++k)                                 /* xp = deepcopy(x[a])              */
         for (int64_t i = 0; i < n; ++i) f->xp[(size_t)k * n + i] = f->x[(size_t)k * n + f->a[i]];
     for (int64_t i = 0; i < n; ++i) {

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMC_LIB") or os.path.join(_HERE, "lib", "libsmchip.so")   # SMC_LIB: profiling builds
 
 MODEL_LG1D, MODEL_SV1D, MODEL_UCSV3D = 1, 2, 3
-FLAG_ANCESTORS, FLAG_NO_RESIDENT = 1, 2
+FLAG_ANCESTORS, FLAG_NO_RESIDENT, FLAG_SYSTEMATIC = 1, 2, 4
 
 # every symbol include/smc_hip.h declares
 EXPORTS = [
@@ -20,7 +20,7 @@ EXPORTS = [
     "smc_log_likelihood", "smc_get_state", "smc_get_logZ", "smc_permute", "smc_copy_from", "smc_slot_bytes", "smc_pack_slots", "smc_unpack_slots", "smc_get_weights_raw", "smc_get_geometry",
     "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_event_overhead_ms", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_get_quantiles", "smc_simulate", "smc_model_dim",
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
-    "smc_host_box_muller", "smc_device_math", "smc_last_error", "smc_version",
+    "smc_host_box_muller", "smc_sys_targets", "smc_device_math", "smc_last_error", "smc_version",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -94,6 +94,7 @@ def lib():
     L.smc_kalman_log_likelihood.argtypes = [_dp, C.c_int64, _dp, C.c_int64, C.c_int, _dp, C.c_int]
     L.smc_get_moments.argtypes = [h, _dp, _dp]
     L.smc_get_quantiles.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
+    L.smc_sys_targets.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_int]
     L.smc_simulate.argtypes = [C.c_int, _dp, C.c_int64, C.c_uint64, _dp, _dp]
     L.smc_model_dim.argtypes = [C.c_int]
     L.smc_model_nraw.argtypes = [C.c_int]
@@ -124,6 +125,13 @@ def _d(a):
 
 def device_count():
     return lib().smc_device_count()
+
+
+def sys_targets(Dtot, n, u, j0, nk, device=-1):
+    """T_{j0+k}, k < nk, of systematic resampling (smc_sys_targets); device < 0: host evaluation."""
+    out = np.zeros(nk, dtype=np.uint64)
+    check(lib().smc_sys_targets(int(Dtot), int(n), int(u), int(j0), int(nk), out.ctypes.data_as(C.POINTER(C.c_uint64)), device))
+    return out
 
 
 def simulate(model_id, raw, T, seed):

@@ -133,6 +133,7 @@ hipError_t launch_count(const FilterView& v, int cur, uint32_t t, int emit_prev,
 }  // namespace smc
 static hipError_t do_count(smc_filter_s* h, uint32_t t, int emit_prev) {
     if (h->v.nseg <= 1) return hipSuccess;   // single segment: every child picks in segment 0
+    if (h->v.systematic) return hipSuccess;  // systematic resampling has no level-1 draw: k_step builds the table itself
 #ifdef SMC_ABLATE
     if (getenv("SMC_DBG_COUNT")) {
         if (!h->dbg_count && hipMalloc((void**)&h->dbg_count, 1024 * 64) == hipSuccess) (void)hipMemset(h->dbg_count, 0, 1024 * 64);
@@ -210,6 +211,8 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     }
 #endif
     h->resident_ok = (v.nseg == 1) && !(flags & SMC_FLAG_NO_RESIDENT);
+    v.systematic = (flags & SMC_FLAG_SYSTEMATIC) ? 1 : 0;
+    v.inv_n = 1.0 / (double)n_x;
 
     const size_t np = (size_t)v.ntheta * (size_t)v.npad, ns = (size_t)v.ntheta * (size_t)v.nseg, nt = (size_t)v.ntheta;
 #define TRY(expr)                                       \
@@ -918,6 +921,30 @@ __global__ void k_device_math(int which, const double* a, const double* b, int64
         r = which == 3 ? z0 : z1;
     } else if (which == 5) r = x / b[i];
     out[i] = r;
+}
+
+__global__ void k_sys_targets(uint64_t Dtot, uint32_t n, uint64_t u, uint64_t j0, int nk, uint64_t* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nk) out[k] = sys_target(sys_base(Dtot, n, 1.0 / (double)n, u, j0), (uint32_t)k);
+}
+// T_{j0+k} = floor(((j0+k) Dtot + mulhi64(u, Dtot)) / n), k < nk <= 8192: the division-free evaluation the
+// systematic kernels use, on the host (device < 0) or on a device - tests compare both with exact integers
+extern "C" int smc_sys_targets(uint64_t Dtot, uint32_t n, uint64_t u, uint64_t j0, int nk, uint64_t* out, int device) {
+    if (!out || nk < 1 || nk > 8192 || n < 1 || n >= (1u << 31) || Dtot >= (1ull << 63) || j0 + (uint64_t)nk > n)
+        return fail(SMC_EINVAL, "smc_sys_targets: bad argument");
+    if (device < 0) {
+        const SysBase sb = sys_base(Dtot, n, 1.0 / (double)n, u, j0);
+        for (int k = 0; k < nk; ++k) out[k] = sys_target(sb, (uint32_t)k);
+        return SMC_OK;
+    }
+    HIPCHK(hipSetDevice(device));
+    uint64_t* d = nullptr;
+    HIPCHK(dalloc(&d, (size_t)nk));
+    hipLaunchKernelGGL(k_sys_targets, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, 0, Dtot, n, u, j0, nk, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, d, (size_t)nk * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return SMC_OK;
 }
 
 extern "C" int smc_device_math(int which, const double* a, const double* b, int64_t n, double* out, int device) {

@@ -67,6 +67,8 @@ struct FilterView {
     const double* y;         // [T] on device (log_likelihood) or nullptr
     double* host_out;        // pinned host mirror [3][ntheta] of (logZ | last_logmu | last_ess): whoever emits
                              //    these also stores them here, so the host needs no copy after its stream sync
+    int systematic;          // opt-in systematic resampling (SMC_FLAG_SYSTEMATIC): selects the SYS kernels
+    double inv_n;            // 1.0 / n  (systematic targets)
     int emit_now;            // single-segment step API: the launch emits (logmu, ess) of ITS OWN weights at the end
                              //    (one workgroup owns the whole filter), so no finalize launch follows
     int want_s2;             // 1: accumulate sum q^2 (ESS) in this launch; 0: its consumer never reads it
@@ -718,7 +720,9 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
 //   normalize(logw)                -> segment epilogue into buffer `cur^1`
 // MULTI = the filter has more than one segment.
 // ---------------------------------------------------------------------------------------------
-template <int MODEL, int THREADS, int NP, bool MULTI>
+// SYS = opt-in systematic resampling (SMC_FLAG_SYSTEMATIC): no level-1 draw, hence no k_count launch; the
+// workgroup builds the segment table itself and child j takes the point T_j = floor((j Dtot + v0) / n).
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false>
 __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_t t, int emit_prev, double yval) {
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     // Issue-early / use-late: every load whose address is known is issued BEFORE the random-number
     // work (Philox + Box-Muller is most of this kernel's VALU), which then runs under the latency.
     // (1) this thread's entry of the children counts and segment sums (MULTI)
-    const bool pre = MULTI && v.nseg_p2 <= THREADS;
+    const bool pre = MULTI && !SYS && v.nseg_p2 <= THREADS;
     unsigned int pre_cnt = 0;
     uint64_t pre_S = 0;
     if (pre && tid < v.nseg) {
@@ -758,11 +762,21 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     uint64_t rr[NQ];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
+        if (SYS) { rr[2 * k] = rr[2 * k + 1] = 0; continue; }
         const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
         const u32x4 rw = SMC_ABL(v, 3) ? u32x4{{pg * 2654435761u, pg ^ t, pg * 40503u, ~pg}} : draw(v.seed, pg, stream, t, SLOT_RESAMPLE);
         rr[2 * k] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
         rr[2 * k + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
     }
+    // systematic: this thread's child indices relative to the workgroup's first child (masked children
+    // j >= n take the last real child's target: they are never stored as real particles)
+    uint32_t kk[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int64_t j = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+        kk[i] = (uint32_t)((j < v.n ? j : v.n - 1) - seg0);
+    }
+    uint64_t Tsys[NQ];   // SYS: the children's targets; after the segment lookup, the in-segment thresholds
 
     // (3) speculative staging (NSTAGE = 3): children are segment-sorted, so the ancestors of the
     //     children at positions [sb*SEG, (sb+1)*SEG) usually sit in segments sb-1..sb+1.  Their loads
@@ -791,7 +805,79 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     int bseg[NQ];
     uint64_t* Cst = nullptr;   // staged segments [NSTAGE][SEG] (MULTI)
     int blo = 0;
-    if (MULTI) {
+    if (MULTI && SYS) {
+        const TableLds L = carve(smem, v.nseg_p2);
+        scr = L.scr;
+        // the segment table of the weights being resampled; workgroup 0 of the filter emits (logmu, ess)
+        // the step's one uniform: drawn by ONE thread (75 VALU instructions the other waves do not spend),
+        // published through LDS across the barriers of the table prologue
+        uint64_t* sysw = L.scr + scr_words(THREADS, NP) - 8;   // tail words nobody else uses
+        if (tid == 0) {
+            const u32x4 uw = draw(v.seed, 0u, stream, t, SLOT_SYS);
+            sysw[0] = ((uint64_t)uw.v[1] << 32) | uw.v[0];
+        }
+        alive = table_prologue<THREADS>(v, cur, th, L, emit_prev && sb == 0, t == 1u, t - 1u);
+        SMC_STAMP(v, 1);
+        const SysBase sbase = sys_base(alive, (uint32_t)v.n, v.inv_n, sysw[0], (uint64_t)seg0);
+        const int64_t jl = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - 1 - seg0;
+        const uint64_t Tfirst = sys_target(sbase, 0u), Tlast = sys_target(sbase, (uint32_t)(jl > 0 ? jl : 0));
+        // targets increase with j: the workgroup's ancestors are the segments [b_lo, b_hi] of its first and
+        // last child.  Usual case: both inside the speculative window - two table reads settle it.
+        int b_lo = 0, b_hi = 0;
+        const int s_hi = spec_lo + NSTAGE - 1 < v.nseg - 1 ? spec_lo + NSTAGE - 1 : v.nseg - 1;
+        if (SPEC && (spec_lo == 0 || L.Dcum[spec_lo - 1] <= Tfirst) && Tlast < L.Dcum[s_hi]) {
+            b_lo = spec_lo;      // a superset of the true range is as good: children search inside it
+            b_hi = s_hi;
+        } else {
+            for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
+                b_lo += (L.Dcum[b_lo + s - 1] <= Tfirst) ? s : 0;
+                b_hi += (L.Dcum[b_hi + s - 1] <= Tlast) ? s : 0;
+            }
+            b_lo = b_lo < v.nseg ? b_lo : v.nseg - 1;
+            b_hi = b_hi < v.nseg ? b_hi : v.nseg - 1;
+            b_hi = b_hi < b_lo ? b_lo : b_hi;
+        }
+        int w0 = 1;
+        while (w0 < b_hi - b_lo + 1) w0 <<= 1;
+        Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
+        const bool spec_ok = SPEC && b_lo >= spec_lo && b_hi < spec_lo + NSTAGE;
+        int st_lo = spec_lo;
+        if (!spec_ok) {   // workgroup-uniform
+            st_lo = b_lo;
+            const int nst = (b_hi - b_lo + 1) < NSTAGE ? (b_hi - b_lo + 1) : NSTAGE;
+#pragma unroll
+            for (int sg = 0; sg < NSTAGE; ++sg) {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) stg[sg][k] = ulonglong2{0, 0};
+                if (sg < nst) {
+                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)(b_lo + sg) * SEG);
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
+                }
+            }
+        }
+        blo = st_lo;
+        int pos[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            Tsys[i] = sys_target(sbase, kk[i]);
+            pos[i] = b_lo;
+        }
+        for (int s = w0 >> 1; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int c = pos[i] + s;
+                pos[i] = (c <= b_hi && L.Dcum[c - 1] <= Tsys[i]) ? c : pos[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            bseg[i] = pos[i];
+            Sseg[i] = 0;
+            const uint64_t base = bseg[i] ? L.Dcum[bseg[i] - 1] : 0;
+            Tsys[i] = sys_threshold(Tsys[i] - base, L.sh[bseg[i]]);   // (C >> sh) > T - base  <=>  C > threshold
+        }
+    } else if (MULTI) {
         const OffsLds L = carve_offs(smem, v.nseg_p2);
         scr = L.scr;
         // the children of this workgroup are consecutive, hence their segments form a range
@@ -857,6 +943,15 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         alive = v.segS[cur][(size_t)th * v.nseg];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) { bseg[i] = 0; Sseg[i] = alive; }
+        if (SYS) {   // one segment: K = kb, shift = SH, table = (S >> SH)
+            const int sh = seg_shift(0.0, 0.0, v.SH);
+            const uint64_t Dtot = seg_Q(alive, sh);
+            const u32x4 uw = draw(v.seed, 0u, stream, t, SLOT_SYS);
+            const SysBase sbase = sys_base(Dtot, (uint32_t)v.n, v.inv_n, ((uint64_t)uw.v[1] << 32) | uw.v[0], 0u);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) Tsys[i] = sys_threshold(sys_target(sbase, kk[i]), sh);
+            alive = Dtot;
+        }
     }
 
     SMC_STAMP(v, 2);
@@ -879,7 +974,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         uint64_t lo;
-        mul64wide(rr[i], Sseg[i], T2[i], lo);
+        if (SYS) T2[i] = Tsys[i];
+        else mul64wide(rr[i], Sseg[i], T2[i], lo);
     }
     if (MULTI) {
 #pragma unroll

@@ -15,25 +15,30 @@ static hipError_t init_t(const FilterView& v, int nxt, double y, hipStream_t s) 
     hipLaunchKernelGGL((k_init<SMC_MODEL, THREADS, NP>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, nxt, y);
     return hipGetLastError();
 }
-template <int THREADS, int NP>
-static hipError_t step_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
+template <int THREADS, int NP, bool SYS>
+static hipError_t step_sys_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
     const size_t lds = step_lds_bytes(v.nseg_p2, THREADS, NP, v.nseg > 1);
     if (lds > 64 * 1024) {
         static bool raised = false;   // per instantiation
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, true>,
+            hipError_t e = hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, true, SYS>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             raised = true;
         }
     }
     if (v.nseg > 1)
-        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, true>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
+        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, true, SYS>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
                            emit_prev, y);
     else
-        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, false>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
+        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, false, SYS>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
                            emit_prev, y);
     return hipGetLastError();
+}
+template <int THREADS, int NP>
+static hipError_t step_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
+    return v.systematic ? step_sys_t<THREADS, NP, true>(v, cur, t, emit_prev, y, s)
+                        : step_sys_t<THREADS, NP, false>(v, cur, t, emit_prev, y, s);
 }
 
 #define SMC_GEO_SWITCH(FN, ...)                                                   \
@@ -63,16 +68,20 @@ hipError_t launch_step<SMC_MODEL>(const FilterView& v, Geo g, int cur, uint32_t 
     SMC_GEO_SWITCH(step_t, v, cur, t, emit_prev, y, s)
 }
 
-template <int THREADS, int NP>
-static hipError_t resident_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
+template <int THREADS, int NP, bool SYS>
+static hipError_t resident_sys_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
     const size_t lds = resident_lds_bytes<SMC_MODEL>(2 * NP * THREADS, THREADS, NP);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_resident<SMC_MODEL, THREADS, NP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_resident<SMC_MODEL, THREADS, NP, SYS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_resident<SMC_MODEL, THREADS, NP>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs);
+    hipLaunchKernelGGL((k_resident<SMC_MODEL, THREADS, NP, SYS>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs);
     return hipGetLastError();
+}
+template <int THREADS, int NP>
+static hipError_t resident_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
+    return v.systematic ? resident_sys_t<THREADS, NP, true>(v, T, recs, s) : resident_sys_t<THREADS, NP, false>(v, T, recs, s);
 }
 
 template <>

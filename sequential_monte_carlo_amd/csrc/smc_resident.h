@@ -15,7 +15,7 @@ __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int n
     return (size_t)lds_padded_len(seg) * 8 * (1 + model_dim<MODEL>::value) + scr_words(threads, np) * 8;
 }
 
-template <int MODEL, int THREADS, int NP>
+template <int MODEL, int THREADS, int NP, bool SYS = false>
 __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepRec* recs /*[ntheta][T]*/) {
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
@@ -24,6 +24,8 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     uint64_t* Cs = (uint64_t*)smem;                       // [SEGP] padded against bank conflicts (lds_pad)
     double* xs = (double*)(smem + (size_t)SEGP * 8);      // [D][SEGP] padded the same way
     uint64_t* scr = (uint64_t*)(smem + (size_t)SEGP * 8 + (size_t)SEGP * 8 * D);
+    uint64_t* usys = scr + scr_words(THREADS, NP) - 8;   // SYS: the steps' uniforms (tail words nobody else uses)
+    constexpr int NU = (THREADS / WAVE) < 8 ? (THREADS / WAVE) : 8;
     const int th = blockIdx.x, tid = threadIdx.x;
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
@@ -41,12 +43,21 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         if (t > 0) {
             // a = resample(weights); xp = x[a]: the NQ searches of a thread advance level by level
             uint64_t T2[NQ];
+            if (SYS) {   // opt-in systematic resampling: child j takes T_j = floor((j S + v0) / n)  (single segment: SH = 0)
+                const SysBase sbase = sys_base(S, (uint32_t)v.n, v.inv_n, usys[(t - 1) % NU], 0u);   // published NU steps at a time
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const u32x4 rw = draw(v.seed, (uint32_t)(tid + k * THREADS), stream, (uint32_t)t, SLOT_RESAMPLE);
-                uint64_t lo;
-                mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], S, T2[2 * k], lo);
-                mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], S, T2[2 * k + 1], lo);
+                for (int i = 0; i < NQ; ++i) {
+                    const int j = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+                    T2[i] = sys_target(sbase, (uint32_t)(j < (int)v.n ? j : (int)v.n - 1));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const u32x4 rw = draw(v.seed, (uint32_t)(tid + k * THREADS), stream, (uint32_t)t, SLOT_RESAMPLE);
+                    uint64_t lo;
+                    mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], S, T2[2 * k], lo);
+                    mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], S, T2[2 * k + 1], lo);
+                }
             }
             // the search carries the padded position as an LDS byte pointer (one ds_read_b64 with an
             // immediate offset per probe); xs is padded like Cs, so the gather uses it as it stands
@@ -110,6 +121,13 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
             StepRec o;
             o.kb = r.kb; o.S = r.S; o.hi = r.hi; o.lo = r.lo;
             rec[t] = o;
+        }
+        if (SYS && (t % NU) == 0 && (tid & (WAVE - 1)) == 0 && tid / WAVE < NU) {
+            // the uniforms of the next NU steps: wave w draws u(t+1+w) - every wave pays one Philox call per NU
+            // steps and no wave runs ahead of the others; the barrier below publishes them
+            const int w = tid / WAVE;
+            const u32x4 uw = draw(v.seed, 0u, stream, (uint32_t)(t + 1 + w), SLOT_SYS);
+            usys[w] = ((uint64_t)uw.v[1] << 32) | uw.v[0];
         }
         __syncthreads();  // Cs, xs complete; scr free
     }

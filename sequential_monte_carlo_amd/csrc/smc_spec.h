@@ -28,6 +28,7 @@ constexpr uint32_t SLOT_RESAMPLE = 0u;   // within-segment pick of child j
 constexpr uint32_t SLOT_NORMAL0 = 1u;    // slots 1..d: state normals
 constexpr uint32_t SLOT_OBS = 8u;        // simulate(): observation noise
 constexpr uint32_t SLOT_COUNT = 9u;      // segment pick of draw i (multi-segment filters)
+constexpr uint32_t SLOT_SYS = 10u;       // the one uniform of a systematic resampling step (opt-in)
 
 constexpr double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
 constexpr double INV_LN2 = 0x1.71547652b82fep+0;
@@ -223,6 +224,65 @@ SMC_HD void mul64wide(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
     lo = (uint64_t)p;
 #endif
 }
+
+// ---- systematic resampling targets (opt-in; SMC_FLAG_SYSTEMATIC) ---------------------------
+// exact q = floor(D / N), r = D mod N for D < 2^63, 1 <= N < 2^31, without an integer divider:
+// double-precision estimates through inv = 1/N (the first off by at most 2^12, the second by at most 1)
+// followed by an exact integer correction of the remainder - the result is exact by construction.
+SMC_HD void divmod_u64_u32(uint64_t D, uint32_t N, double inv, uint64_t& q, uint32_t& r) {
+    if ((N & (N - 1u)) == 0u) {   // power of two: the common particle counts
+        const int sft = __builtin_ctz(N);
+        q = D >> sft;
+        r = (uint32_t)(D & (uint64_t)(N - 1u));
+        return;
+    }
+    uint64_t q1 = (uint64_t)((double)D * inv);
+    int64_t r1 = (int64_t)(D - q1 * (uint64_t)N);          // |r1| < 2^44: exact in a double
+    const int64_t q2 = (int64_t)floor((double)r1 * inv);
+    q1 += (uint64_t)q2;
+    r1 -= q2 * (int64_t)N;
+    if (r1 < 0) { q1 -= 1; r1 += N; }
+    if (r1 >= (int64_t)N) { q1 += 1; r1 -= N; }
+    q = q1;
+    r = (uint32_t)r1;
+}
+// T_j = floor((j * Dtot + v0) / n), v0 = mulhi64(u, Dtot), for the children j = j0 + k, k < 2^13:
+// with Dtot = dq n + dr, v0 = q0 n + r0 and r0 + j0 dr = qa n + ra,
+//     T_j = (q0 + j0 dq + qa) + k dq + floor((ra + k dr) / n),   ra + k dr < 2^44.
+struct SysBase {
+    uint64_t Tbase, dq;
+    double inv;
+    uint32_t ra, dr, n;
+};
+// inv = 1.0 / (double)n (a per-filter constant: the host passes it in)
+SMC_HD SysBase sys_base(uint64_t Dtot, uint32_t n, double inv, uint64_t u, uint64_t j0) {
+    uint64_t v0, lo;
+    mul64wide(u, Dtot, v0, lo);
+    SysBase sb;
+    sb.n = n;
+    sb.inv = inv;
+    uint64_t q0, qa;
+    uint32_t r0;
+    divmod_u64_u32(Dtot, n, sb.inv, sb.dq, sb.dr);
+    divmod_u64_u32(v0, n, sb.inv, q0, r0);
+    divmod_u64_u32((uint64_t)r0 + j0 * (uint64_t)sb.dr, n, sb.inv, qa, sb.ra);
+    sb.Tbase = q0 + j0 * sb.dq + qa;
+    return sb;
+}
+SMC_HD uint64_t sys_target(const SysBase& sb, uint32_t k) {
+    const uint64_t e = (uint64_t)sb.ra + (uint64_t)k * sb.dr;   // < 2^44
+    uint64_t qe;
+    if ((sb.n & (sb.n - 1u)) == 0u) {
+        qe = e >> __builtin_ctz(sb.n);
+    } else {
+        qe = (uint64_t)((double)e * sb.inv);                    // floor(e / n) or one off: settle it exactly
+        const int64_t rem = (int64_t)(e - qe * (uint64_t)sb.n);
+        qe = rem < 0 ? qe - 1 : (rem >= (int64_t)sb.n ? qe + 1 : qe);
+    }
+    return sb.Tbase + (uint64_t)k * sb.dq + qe;
+}
+// (C >> sh) > T2  <=>  C > sys_threshold(T2, sh)
+SMC_HD uint64_t sys_threshold(uint64_t T2, int sh) { return sh < 64 ? ((T2 + 1) << sh) - 1 : 0; }
 
 SMC_HD double u128_to_double(uint64_t hi, uint64_t lo) { return (double)hi * TWO_P64 + (double)lo; }
 

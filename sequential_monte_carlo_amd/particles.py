@@ -41,10 +41,12 @@ def resample(w, N=None, seed=None, stream=0, t=0, device=0):
 class _Filters:
     """Device state shared by the Particles / Weights views of one bootstrap_filter call."""
 
-    def __init__(self, N, models, seed, seg, device, streams, ancestors):
+    def __init__(self, N, models, seed, seg, device, streams, ancestors, resampler="multinomial"):
         mid, raw = params_matrix(models)
         self.single = not isinstance(models, (list, tuple))
-        flags = _lib.FLAG_ANCESTORS if ancestors else 0
+        if resampler not in ("multinomial", "systematic"):
+            raise ValueError("resampler must be 'multinomial' (the reference's law) or 'systematic' (opt-in)")
+        flags = (_lib.FLAG_ANCESTORS if ancestors else 0) | (_lib.FLAG_SYSTEMATIC if resampler == "systematic" else 0)
         self.h = _lib.Handle(mid, raw.shape[0], N, seg=seg, seed=seed, device=device, flags=flags)
         self.h.set_params(raw)
         if streams is not None:
@@ -114,11 +116,12 @@ class Weights:
         return self._f.h.n_x
 
 
-def bootstrap_filter(N, y, model, seed=None, seg=0, device=0, streams=None, ancestors=False):
-    """x, w, logmu = bootstrap_filter(N, y[1], model)   particles.jl:87-105"""
+def bootstrap_filter(N, y, model, seed=None, seg=0, device=0, streams=None, ancestors=False, resampler="multinomial"):
+    """x, w, logmu = bootstrap_filter(N, y[1], model)   particles.jl:87-105
+    resampler="systematic" (opt-in, not the reference's law) applies to the following bootstrap_filter_ steps."""
     if seed is None:
         seed = next(_seed_counter)
-    f = _Filters(int(N), model, seed, seg, device, streams, ancestors)
+    f = _Filters(int(N), model, seed, seg, device, streams, ancestors, resampler)
     logmu = f.h.init(float(y))
     return Particles(f), Weights(f), f.out(logmu)
 
@@ -134,12 +137,14 @@ def bootstrap_filter_(states, weights, y, model):
     return f.out(logmu), Weights(f), f.out(ess)
 
 
-def log_likelihood(N, y, model, seed=None, seg=0, device=0, streams=None, ancestors=False, trace=False):
+def log_likelihood(N, y, model, seed=None, seg=0, device=0, streams=None, ancestors=False, trace=False,
+                   resampler="multinomial"):
     """x, w, logZ = log_likelihood(N, y, model)   particles.jl:132-147
-    trace=True additionally returns the per-step (logmu_t, ess_t)."""
+    trace=True additionally returns the per-step (logmu_t, ess_t).  resampler="systematic": opt-in systematic
+    resampling (same expectation, lower variance, one launch per step for big filters; not the reference's law)."""
     if seed is None:
         seed = next(_seed_counter)
-    f = _Filters(int(N), model, seed, seg, device, streams, ancestors)
+    f = _Filters(int(N), model, seed, seg, device, streams, ancestors, resampler)
     y = np.ascontiguousarray(y, dtype=np.float64)
     if trace:
         logZ, lm, es = f.h.log_likelihood(y, trace=True)

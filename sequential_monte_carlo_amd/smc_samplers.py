@@ -35,15 +35,16 @@ def _rows(models):
 class HipBackend:
     """Runs the batched inner filters on one GPU through the C ABI (no CPU fallback)."""
 
-    def __init__(self, device=0, seg=0):
+    def __init__(self, device=0, seg=0, resampler="multinomial"):
         self.device, self.seg = device, seg
+        self.flags = _lib.FLAG_SYSTEMATIC if resampler == "systematic" else 0   # opt-in; default = the reference's law
         self._handles = {}
 
     def _handle(self, key, model_id, n_theta, N, seed):
         k = (key, model_id, n_theta, N)
         h = self._handles.get(k)
         if h is None:
-            h = _lib.Handle(model_id, n_theta, N, seg=self.seg, seed=seed, device=self.device)
+            h = _lib.Handle(model_id, n_theta, N, seg=self.seg, seed=seed, device=self.device, flags=self.flags)
             self._handles[k] = h
         h.reseed(seed)
         return h

@@ -361,6 +361,84 @@ def test_many_segments_per_thread_bit_exact(L, ob):
         h.close()
 
 
+# ---- opt-in systematic resampling (SMC_FLAG_SYSTEMATIC) ------------------------------------------
+def test_systematic_targets_on_device_are_exact(L):
+    rng = np.random.default_rng(11)
+    cases = [((1 << 63) - 1, (1 << 31) - 1, 2**64 - 1, (1 << 31) - 1 - 8192, 8192), ((1 << 62) + 12345, 1 << 20, 987654321987654321, 4096, 4096),
+             (5, 3, 2**63 + 11, 0, 3), (0, 1000, 77, 0, 1000)]
+    for _ in range(40):
+        n = int(rng.integers(1, 1 << 31)) if rng.random() < 0.7 else 1 << int(rng.integers(0, 31))
+        D = int(rng.integers(0, 1 << 63)) >> int(rng.integers(0, 62))
+        nk = int(min(n, rng.integers(1, 8193)))
+        cases.append((D, n, int(rng.integers(0, 1 << 64, dtype=np.uint64)), int(rng.integers(0, n - nk + 1)), nk))
+    for D, n, u, j0, nk in cases:
+        v0 = (u * D) >> 64
+        want = [((j0 + k) * D + v0) // n for k in range(nk)]
+        assert [int(g) for g in L.sys_targets(D, n, u, j0, nk, device=0)] == want, (D, n, u, j0, nk)
+
+
+def test_systematic_filters_bit_exact(L, ob):
+    """SMC_FLAG_SYSTEMATIC == the oracle's systematic resampler, bit for bit: resident and step kernels,
+    one and many segments, power-of-two and awkward Nx, all three models, degenerate weights."""
+    cfgs = [(1, LG, 1024, 0, 0), (1, LG, 1024, 0, L.FLAG_NO_RESIDENT), (1, LG, 1000, 256, 0), (2, SV, 777, 256, 0),
+            (3, UC, 3000, 1024, 0), (3, UC, 512, 0, 0), (1, LG, 5000, 2048, 0), (2, SV, 70001, 2048, 0), (1, LG, 65536, 1024, 0),
+            (1, [0.9, 1.0, 1.0, 1e-5, 0.0, 4.0], 40000, 1024, 0)]
+    for model, raw, n, seg, fl in cfgs:
+        _, y = ob.simulate(model, raw if raw[3:4] != [1e-5] else [0.9, 1.0, 1.0, 0.5, 0.0, 4.0], 9, 7)
+        h = L.Handle(model, 2, n, seg=seg, seed=23, flags=L.FLAG_ANCESTORS | L.FLAG_SYSTEMATIC | fl)
+        h.set_params(np.tile(raw, (2, 1)))
+        logZ, lm, es = h.log_likelihood(y, trace=True)
+        x, w, a = h.state()
+        for th in range(2):
+            f = ob.Filter(model, raw, n, seg=seg, seed=23, stream=th, systematic=True)
+            z, olm, oes = f.log_likelihood(y, trace=True)
+            ox, ow, oa, _ = f.state()
+            ctx = (model, n, seg, fl, th)
+            assert bits([logZ[th]])[0] == bits([z])[0] and same(lm[:, th], olm) and same(es[:, th], oes), ctx
+            assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa), ctx
+            assert np.all(np.diff(a[th]) >= 0), ctx                       # children fully sorted by ancestor
+        h.close()
+    # the step API, and the defining property of systematic resampling: #children in {floor, ceil}(N w)
+    n = 6000
+    _, y = ob.simulate(1, LG, 5, 3)
+    h = L.Handle(1, 1, n, seg=1024, seed=5, flags=L.FLAG_ANCESTORS | L.FLAG_SYSTEMATIC)
+    h.set_params(LG)
+    f = ob.Filter(1, LG, n, seg=1024, seed=5, systematic=True)
+    assert same(h.init(y[0]), [f.bootstrap_filter(y[0])])
+    for t in range(1, 5):
+        _, w_before, _ = h.state(want_anc=False)
+        lm, ess = h.step(y[t])
+        olm, oess = f.step(y[t])
+        assert same(lm, [olm]) and same(ess, [oess])
+        cnt = np.bincount(h.state()[2][0], minlength=n)
+        assert np.all(cnt >= np.floor(n * w_before[0] - 1e-6)) and np.all(cnt <= np.ceil(n * w_before[0] + 1e-6))
+    h.close()
+
+
+def test_systematic_is_unbiased_against_kalman(L):
+    """The systematic kernels against the reference's exact Kalman likelihood (tests/golden/kalman_lg.json):
+    E[exp(logZ - logZ_KF)] = 1, and no more variance than the multinomial kernels at the same size."""
+    import json, os
+    from conftest import GOLDEN
+    kf = json.load(open(os.path.join(GOLDEN, "kalman_lg.json")))["cases"]["T100"]["logZ_kf"]
+    _, y = L.simulate(1, LG, 100, 1998)
+    K = 256
+    out = {}
+    for name, fl in (("sys", L.FLAG_SYSTEMATIC), ("mult", 0)):
+        zs = []
+        for seg, seed in ((0, 50), (256, 51)):       # resident single segment; four segments through k_step
+            h = L.Handle(1, K, 1024, seg=seg, seed=seed, flags=fl)
+            h.set_params(np.tile(LG, (K, 1)))
+            zs.append(h.log_likelihood(y))
+            h.close()
+        out[name] = zs
+    for z in out["sys"]:
+        r = np.exp(z - kf)
+        assert abs(r.mean() - 1.0) < 4.5 * r.std(ddof=1) / np.sqrt(K)
+        assert abs(z.mean() + 0.5 * z.var(ddof=1) - kf) < 4.5 * z.std(ddof=1) / np.sqrt(K)
+    assert np.concatenate(out["sys"]).var(ddof=1) < 1.2 * np.concatenate(out["mult"]).var(ddof=1)
+
+
 def test_step_api_multi_segment_with_permute_and_copy(L, ob):
     """smc_step on multi-segment filters interleaved with smc_permute / smc_copy_from."""
     _, y = ob.simulate(1, LG, 10, 1998)

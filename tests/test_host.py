@@ -63,6 +63,26 @@ def test_auto_seg_equals_oracle(L, ob):
         assert (n + L.lib().smc_auto_seg(n) - 1) // L.lib().smc_auto_seg(n) <= 4096     # smc_create's segment limit
 
 
+def test_systematic_targets_are_exact(L):
+    """The kernels' division-free T_j = floor((j Dtot + mulhi64(u, Dtot)) / n) against Python's exact integers:
+    powers of two and awkward n, tiny and huge Dtot, every region of j."""
+    rng = np.random.default_rng(7)
+    cases = [(1, 1, 0, 0, 1), (5, 3, 2**63 + 11, 0, 3), ((1 << 63) - 1, (1 << 31) - 1, 2**64 - 1, (1 << 31) - 1 - 8192, 8192),
+             ((1 << 62) + 12345, 1 << 20, 123456789123456789, (1 << 20) - 2048, 2048), (977, 1 << 20, 2**63, 4096, 4096)]
+    for _ in range(300):
+        n = int(rng.integers(1, 1 << 31)) if rng.random() < 0.7 else 1 << int(rng.integers(0, 31))
+        D = int(rng.integers(0, 1 << 63)) >> int(rng.integers(0, 62))
+        nk = int(min(n, rng.integers(1, 8193)))
+        j0 = int(rng.integers(0, n - nk + 1))
+        cases.append((D, n, int(rng.integers(0, 1 << 64, dtype=np.uint64)), j0, nk))
+    for D, n, u, j0, nk in cases:
+        got = L.sys_targets(D, n, u, j0, nk)
+        v0 = (u * D) >> 64
+        want = [((j0 + k) * D + v0) // n for k in range(nk)]
+        assert [int(g) for g in got] == want, (D, n, u, j0, nk)
+        assert not D or max(want) < D
+
+
 def test_argument_errors_are_reported_not_fatal(L):
     lib = L.lib()
     h = C.c_void_p()

@@ -162,6 +162,31 @@ def test_particle_filter_pinned_by_kalman(ob):
     assert z4.var(ddof=1) < 0.6 * z.var(ddof=1)
 
 
+def test_systematic_resampling_option(ob):
+    """The opt-in systematic resampler of the oracle: children sorted by ancestor, every particle gets
+    floor(N w) or ceil(N w) children (the defining property), and the likelihood estimate stays unbiased
+    against the reference's exact Kalman likelihood with no more variance than multinomial resampling."""
+    _, y = ob.simulate(ob.LG1D, LG, 100, 1998)
+    for n, seg in ((1000, 256), (1024, 0), (5000, 1024), (777, 256), (2049, 2048)):
+        f = ob.Filter(ob.LG1D, LG, n, seg=seg, seed=3, systematic=True)
+        f.bootstrap_filter(y[0])
+        for t in range(1, 4):
+            _, w, _, _ = f.state()
+            f.step(y[t])
+            a = f.state()[2]
+            cnt = np.bincount(a, minlength=n)
+            assert np.all(np.diff(a) >= 0) and cnt.sum() == n
+            assert np.all(cnt >= np.floor(n * w - 1e-6)) and np.all(cnt <= np.ceil(n * w + 1e-6))
+    kf = json.load(open(os.path.join(GOLDEN, "kalman_lg.json")))["cases"]["T100"]["logZ_kf"]
+    K = 96
+    zs = np.array([ob.Filter(ob.LG1D, LG, 1024, seg=256, seed=1000 + s, systematic=True).log_likelihood(y) for s in range(K)])
+    zm = np.array([ob.Filter(ob.LG1D, LG, 1024, seg=256, seed=1000 + s).log_likelihood(y) for s in range(K)])
+    r = np.exp(zs - kf)
+    assert abs(r.mean() - 1.0) < 4.5 * r.std(ddof=1) / np.sqrt(K)
+    assert abs(zs.mean() + 0.5 * zs.var(ddof=1) - kf) < 4.5 * zs.std(ddof=1) / np.sqrt(K)
+    assert zs.var(ddof=1) < 1.3 * zm.var(ddof=1)
+
+
 def test_edge_cases(ob):
     # Nx = 1, odd Nx, Nx not a multiple of seg, T = 1
     _, y = ob.simulate(ob.LG1D, LG, 5, 1998)
