@@ -9,10 +9,11 @@ from sequential_monte_carlo_amd.smc_samplers import _rows as params_matrix
 
 
 class OracleHandle:
-    def __init__(self, model_id, raws, N, seg, seed, streams):
-        self.model_id, self.N, self.seg = model_id, N, seg
+    def __init__(self, model_id, raws, N, seg, seed, streams, systematic=False):
+        self.model_id, self.N, self.seg, self.systematic = model_id, N, seg, systematic
         self.n_theta = raws.shape[0]
-        self.f = [ob.Filter(model_id, raws[m], N, seg=seg, seed=seed, stream=int(streams[m])) for m in range(self.n_theta)]
+        self.f = [ob.Filter(model_id, raws[m], N, seg=seg, seed=seed, stream=int(streams[m]), systematic=systematic)
+                  for m in range(self.n_theta)]
 
     def set_params(self, raws):
         for m, f in enumerate(self.f):
@@ -60,17 +61,17 @@ class OracleHandle:
 
 
 class OracleBackend:
-    def __init__(self, seg=0):
-        self.seg = seg
+    def __init__(self, seg=0, resampler="multinomial"):
+        self.seg, self.systematic = seg, resampler == "systematic"
 
     def log_likelihood(self, models, N, y, seed, streams, key="prop"):
         mid, raw = params_matrix(models)
-        h = OracleHandle(mid, raw, N, self.seg, seed, streams)
+        h = OracleHandle(mid, raw, N, self.seg, seed, streams, self.systematic)
         return h.log_likelihood(np.asarray(y, dtype=np.float64)), h
 
     def init(self, models, N, y1, seed, streams, key="main"):
         mid, raw = params_matrix(models)
-        h = OracleHandle(mid, raw, N, self.seg, seed, streams)
+        h = OracleHandle(mid, raw, N, self.seg, seed, streams, self.systematic)
         return h.init(float(y1)), h
 
     def close(self):

@@ -87,6 +87,19 @@ def test_density_tempered_hip_equals_oracle_backend():
     assert np.array_equal(bits(sh.omega), bits(so.omega)) and sh.psteps == so.psteps
 
 
+def test_samplers_with_systematic_resampling_option():
+    """HipBackend(resampler="systematic") == the oracle backend with its systematic resampler, whole runs."""
+    for online in (False, True):
+        sh, th, a_h, b_h = _run(smc.smc_samplers.HipBackend(resampler="systematic"), online=online)
+        so, to, a_o, b_o = _run(OracleBackend(resampler="systematic"), online=online)
+        assert th == to
+        assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+        if online:
+            assert np.array_equal(bits(a_h), bits(a_o)) and np.array_equal(bits(b_h), bits(b_o))
+    sm, _, _, _ = _run(smc.smc_samplers.HipBackend(), online=False)
+    assert not np.array_equal(bits(sh.logZ), bits(sm.logZ))          # and it is a different sampler than the default
+
+
 def test_smc2_online_hip_equals_oracle_backend():
     """smc² / smc²! incl. resample!(permute), PMMH accept (copy_from) on the device."""
     sh, th, xh, wh = _run(smc.smc_samplers.HipBackend(), online=True)
