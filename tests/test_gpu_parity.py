@@ -437,6 +437,17 @@ def test_systematic_is_unbiased_against_kalman(L):
         assert abs(r.mean() - 1.0) < 4.5 * r.std(ddof=1) / np.sqrt(K)
         assert abs(z.mean() + 0.5 * z.var(ddof=1) - kf) < 4.5 * z.std(ddof=1) / np.sqrt(K)
     assert np.concatenate(out["sys"]).var(ddof=1) < 1.2 * np.concatenate(out["mult"]).var(ddof=1)
+    # full size (C2 shape, T shortened): against the exact likelihood, ancestors sorted, weights normalised
+    from oracle import kalman
+    n, T = 1 << 20, 200
+    _, y2 = L.simulate(1, LG, T, 1998)
+    h = L.Handle(1, 1, n, seed=9, flags=L.FLAG_SYSTEMATIC | L.FLAG_ANCESTORS)
+    h.set_params(LG)
+    z = h.log_likelihood(y2)[0]
+    assert abs(z - kalman.log_likelihood(y2, *LG[:4], x0=LG[4], sigma0=LG[5], predict_first=False)[2]) < 0.05
+    _, w, a = h.state()
+    assert np.all(np.diff(a[0].astype(np.int64)) >= 0) and abs(w.sum() - 1.0) < 1e-10
+    h.close()
 
 
 def test_step_api_multi_segment_with_permute_and_copy(L, ob):
