@@ -66,6 +66,7 @@ typedef unsigned __int128 u128;
 #define SLOT_OBS 8u            /* simulate(): observation noise                           */
 #define SLOT_COUNT 9u          /* segment pick of draw i (multi-segment filters only)     */
 #define SLOT_SYS 10u           /* the one uniform of a systematic resampling step (opt-in) */
+#define SLOT_BREAK 16u         /* break points of the blocks: 16+2i normal, 17+2i uniform, i < 8; pair = block */
 
 static const double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
 static const double LOG2PI = 0x1.d67f1c864beb5p+0;
@@ -511,8 +512,58 @@ static void weights_normalize(orc_weights* W, const double* logw) {
     W->ess = R ? Dd * Dd / Rd : 0.0;
 }
 
-/* a = resample(weights): ancestors of all n children, exactly Multinomial(n, w), children sorted
- * by ancestor segment.  (seed, stream, t) select the Philox counters. */
+/* Gamma(m, 1), integer shape m >= 1, in 2^-32 fixed point (Marsaglia & Tsang 2000: d = m - 1/3,
+ * c = 1/sqrt(9d); x ~ N(0,1), v = (1 + c x)^3, accept if u < 1 - 0.0331 x^4 or
+ * log u < x^2/2 + d (1 - v + log v)).  Counter-based: attempt i of block w uses slots 16+2i, 17+2i. */
+static uint64_t gamma_fix(uint64_t seed, uint32_t w, uint32_t stream, uint32_t t, int64_t m) {
+    const double d = (double)m - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double G = d;                                   /* (all 8 attempts rejected: probability ~1e-15) */
+    for (uint32_t it = 0; it < 8; ++it) {
+        double z[2];
+        normal_pair(seed, w, stream, t, SLOT_BREAK + 2 * it, z);
+        const double x = z[0], vv = 1.0 + c * x;
+        if (!(vv > 0.0)) continue;
+        const double v3 = vv * vv * vv, x2 = x * x;
+        uint32_t wd[4];
+        draw(seed, w, stream, t, SLOT_BREAK + 2 * it + 1, wd);
+        const double u = (double)((((((uint64_t)wd[1] << 32) | wd[0]) >> 11)) + 1) * TWO_M53;
+        if (u < 1.0 - 0.0331 * (x2 * x2) || orc_log(u) < 0.5 * x2 + d * ((1.0 - v3) + orc_log(v3))) { G = d * v3; break; }
+    }
+    const uint64_t g = (uint64_t)rne_pos(G * 0x1p32);
+    return g ? g : 1;
+}
+
+/* Break points of the n sorted iid uniforms of a resampling step at the block boundaries (block =
+ * the seg consecutive children a workgroup owns).  With E_i iid Exp(1), the order statistics are
+ * U_(k) = (E_1+..+E_k)/(E_1+..+E_{n+1}); a block of m ranks contributes a Gamma(m) to these sums, so
+ * the block's largest uniform is F_{w+1} = (g_0+..+g_w)/(g_0+..+g_{B-1}+e) and - given the break
+ * points - the other m-1 uniforms of the block are iid on (F_w, F_{w+1}).  F in 2^-64 fixed point. */
+static void resample_breaks(const orc_weights* W, uint64_t seed, uint32_t stream, uint32_t t, uint64_t* F /*[nseg+1]*/) {
+    const int B = W->nseg;
+    uint64_t S = 0;
+    for (int w = 0; w < B; ++w) {
+        int64_t m = W->n - (int64_t)w * W->seg;
+        if (m > W->seg) m = W->seg;
+        F[w + 1] = gamma_fix(seed, (uint32_t)w, stream, t, m);      /* g_w for now */
+        S += F[w + 1];
+    }
+    uint32_t wd[4];
+    draw(seed, (uint32_t)B, stream, t, SLOT_BREAK + 1, wd);
+    const double u = (double)((((((uint64_t)wd[1] << 32) | wd[0]) >> 11)) + 1) * TWO_M53;
+    uint64_t e = (uint64_t)rne_pos(-orc_log(u) * 0x1p32);
+    S += e ? e : 1;
+    uint64_t P = 0;
+    F[0] = 0;
+    for (int w = 0; w < B; ++w) {
+        P += F[w + 1];
+        F[w + 1] = (uint64_t)((((u128)P) << 64) / S);
+    }
+}
+
+/* a = resample(weights): ancestors of all n children, exactly Multinomial(n, w) - the n iid uniforms
+ * are generated block by block between their break points (above), so the children come out sorted by
+ * block of the weight CDF; inside a block the order is iid.  One segment: n iid picks, no breaks.
+ * (seed, stream, t) select the Philox counters. */
 static void weights_resample(orc_weights* W, uint64_t seed, uint32_t stream, uint32_t t, int64_t* a) {
     const int64_t n = W->n;
     uint64_t r[2];
@@ -520,24 +571,34 @@ static void weights_resample(orc_weights* W, uint64_t seed, uint32_t stream, uin
         for (int64_t i = 0; i < n; ++i) a[i] = i;
         return;
     }
-    if (W->nseg > 1) {                                           /* level 1: count the segment picks */
-        for (int b = 0; b < W->nseg; ++b) W->cnt[b] = 0;
-        for (int64_t i = 0; i < n; ++i) {
-            if (!(i & 1)) resample_pair(seed, i >> 1, stream, t, SLOT_COUNT, r);
-            uint64_t T1 = (uint64_t)(((u128)r[i & 1] * W->Dtot) >> 64);
-            W->cnt[upper_bound_u64(W->Dcum, W->nseg, T1)] += 1;
+    if (W->nseg == 1) {
+        for (int64_t j = 0; j < n; ++j) {
+            if (!(j & 1)) resample_pair(seed, j >> 1, stream, t, SLOT_RESAMPLE, r);
+            uint64_t T2 = (uint64_t)(((u128)r[j & 1] * W->S[0]) >> 64);
+            a[j] = upper_bound_u64(W->C, W->seg, T2);
         }
-    } else {
-        W->cnt[0] = n;
+        return;
     }
-    int b = 0;
-    int64_t end = W->cnt[0];                                     /* children [.., end) belong to segment b */
-    for (int64_t j = 0; j < n; ++j) {                            /* level 2: iid pick inside the segment */
-        while (j >= end) end += W->cnt[++b];
-        if (!(j & 1)) resample_pair(seed, j >> 1, stream, t, SLOT_RESAMPLE, r);
-        uint64_t T2 = (uint64_t)(((u128)r[j & 1] * W->S[b]) >> 64);
-        a[j] = (int64_t)b * W->seg + upper_bound_u64(W->C + (size_t)b * W->seg, W->seg, T2);
+    uint64_t* F = (uint64_t*)malloc(8 * ((size_t)W->nseg + 1));
+    resample_breaks(W, seed, stream, t, F);
+    for (int w = 0; w < W->nseg; ++w) {
+        const uint64_t lo = (uint64_t)(((u128)F[w] * W->Dtot) >> 64), hi = (uint64_t)(((u128)F[w + 1] * W->Dtot) >> 64);
+        int64_t m = n - (int64_t)w * W->seg;
+        if (m > W->seg) m = W->seg;
+        for (int64_t k = 0; k < m; ++k) {
+            const int64_t j = (int64_t)w * W->seg + k;
+            if (!(j & 1)) resample_pair(seed, j >> 1, stream, t, SLOT_RESAMPLE, r);
+            const uint64_t T = (k == m - 1) ? hi : lo + (uint64_t)(((u128)r[j & 1] * (hi - lo)) >> 64);
+            const int b = (int)upper_bound_u64(W->Dcum, W->nseg, T);
+            const uint64_t T2 = T - (b ? W->Dcum[b - 1] : 0);
+            const double dk = W->K - W->kb[b];
+            int sh = (dk >= 0.0 && dk < 64.0) ? (int)dk + W->SH : 64;
+            if (sh > 64) sh = 64;
+            const uint64_t thr = sh < 64 ? ((T2 + 1) << sh) - 1 : 0;      /* (C >> sh) > T2  <=>  C > thr */
+            a[j] = (int64_t)b * W->seg + upper_bound_u64(W->C + (size_t)b * W->seg, W->seg, thr);
+        }
     }
+    free(F);
 }
 
 /* OPT-IN alternative to resample(): systematic resampling (one uniform u per step; child j takes the

@@ -95,6 +95,49 @@ __global__ __launch_bounds__(THREADS) void k_moments(FilterView v, int cur, doub
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_breaks: the break points of the resampling steps t0 .. t0+gridDim.x-1 of every filter (smc_spec.h
+// "break points"): F[(tt * ntheta + th) * (nseg + 1) + w], 2^-64 fixed point, F[..][0] = 0.  They depend
+// on (seed, stream, t, block sizes) only - never on the particles - so this runs ahead of the steps, off
+// the critical path.  grid (steps, ntheta); one Gamma variate per block, an integer scan, one long division.
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_breaks(FilterView v, uint32_t t0, uint64_t* F) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* g = (uint64_t*)smem;               // [nseg + 1]
+    uint64_t* wt = g + v.nseg + 1;               // [THREADS / WAVE]
+    constexpr int NW = THREADS / WAVE;
+    const int tt = blockIdx.x, th = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const uint32_t t = t0 + (uint32_t)tt, stream = v.stream[th];
+    const int B = v.nseg;
+    for (int w = tid; w < B; w += THREADS) {
+        int64_t m = v.n - (int64_t)w * v.seg;
+        m = m > v.seg ? v.seg : m;
+        g[w] = gamma_fix(v.seed, (uint32_t)w, stream, t, m);
+    }
+    if (tid == 0) g[B] = exp1_fix(v.seed, (uint32_t)B, stream, t);
+    __syncthreads();
+    const int E = (B + THREADS - 1) / THREADS;   // consecutive entries per thread
+    uint64_t run = 0;
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        if (i < B) { run += g[i]; g[i] = run; }
+    }
+    const uint64_t incl = wave_incl_scan(run, lane);
+    if (lane == WAVE - 1) wt[wave] = incl;
+    __syncthreads();
+    uint64_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { off += w < wave ? wt[w] : 0; tot += wt[w]; }
+    const uint64_t excl = off + incl - run, S = tot + g[B];
+    uint64_t* out = F + ((size_t)tt * v.ntheta + th) * ((size_t)B + 1);
+    if (tid == 0) out[0] = 0;
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        if (i < B) out[i + 1] = div_frac64(g[i] + excl, S);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Weighted quantiles of one state coordinate (quantile(x, weights(w), p) of
 // examples/inflation_example.jl:45).  Integer definition (see include/smc_hip.h smc_get_quantiles):
 // W_i = q_i >> sh_b, T = floor(p * sum W); result = smallest value v with sum{W_i : x_i <= v} > T.

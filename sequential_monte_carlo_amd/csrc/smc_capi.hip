@@ -46,7 +46,8 @@ struct smc_filter_s {
     double* d_wdense = nullptr;
     StepRec* d_recs = nullptr;
     double* h_pin = nullptr;                   // pinned host mirror [3][ntheta]: logZ | last_logmu | last_ess
-    unsigned long long* dbg_count = nullptr;   // diagnostic builds only
+    uint64_t* d_brk = nullptr;                 // break points of the steps [v.brk_t0, v.brk_t0 + brk_count)
+    uint32_t brk_cap = 0, brk_count = 0;
     int64_t reccap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -120,29 +121,29 @@ static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) 
     }
     return hipErrorInvalidValue;
 }
-namespace smc {
-hipError_t launch_count(const FilterView& v, int cur, uint32_t t, int emit_prev, hipStream_t s) {
-    constexpr int TH = 512;   // workgroup size of k_count (tuning: 256 / 512 / 1024)
-    const int64_t npairs = (v.n + 1) >> 1;
-    int64_t ncw = (npairs + 2 * TH - 1) / (2 * TH);   // one trip (2 pairs = 4 draws) per thread
-    ncw = ncw < 1 ? 1 : (ncw > 1024 ? 1024 : ncw);
-    hipLaunchKernelGGL((k_count<TH>), dim3((unsigned)ncw, v.ntheta), dim3(TH), count_lds_bytes(v.nseg_p2, TH), s, v, cur, t,
-                       emit_prev);
-    return hipGetLastError();
-}
-}  // namespace smc
-static hipError_t do_count(smc_filter_s* h, uint32_t t, int emit_prev) {
-    if (h->v.nseg <= 1) return hipSuccess;   // single segment: every child picks in segment 0
-    if (h->v.systematic) return hipSuccess;  // systematic resampling has no level-1 draw: k_step builds the table itself
-#ifdef SMC_ABLATE
-    if (getenv("SMC_DBG_COUNT")) {
-        if (!h->dbg_count && hipMalloc((void**)&h->dbg_count, 1024 * 64) == hipSuccess) (void)hipMemset(h->dbg_count, 0, 1024 * 64);
-        FilterView vv = h->v;
-        vv.dbg = h->dbg_count;
-        return launch_count(vv, h->cur, t, emit_prev, h->stream);
+// Break points of the multinomial resampling steps (multi-segment filters; smc_spec.h): computed by k_breaks
+// for a window of steps ahead of time - they depend on (seed, stream, t) only.  Called before every step
+// launch; almost always a no-op.
+static hipError_t ensure_breaks(smc_filter_s* h, uint32_t t, uint32_t t_end) {
+    FilterView& v = h->v;
+    if (v.nseg <= 1 || v.systematic) return hipSuccess;
+    if (h->brk_count && t >= v.brk_t0 && t < v.brk_t0 + h->brk_count) return hipSuccess;
+    const size_t per_step = (size_t)v.ntheta * ((size_t)v.nseg + 1);
+    if (!h->d_brk) {
+        size_t steps = ((size_t)32 << 20) / (per_step * 8);    // <= 32 MiB of break points at a time
+        steps = steps < 1 ? 1 : (steps > 1024 ? 1024 : steps);
+        hipError_t e = hipMalloc((void**)&h->d_brk, steps * per_step * 8);
+        if (e != hipSuccess) return e;
+        h->brk_cap = (uint32_t)steps;
+        v.brk = h->d_brk;
     }
-#endif
-    return launch_count(h->v, h->cur, t, emit_prev, h->stream);
+    uint32_t cnt = t_end > t ? t_end - t : 1;                  // no further than the caller will go
+    cnt = cnt > h->brk_cap ? h->brk_cap : cnt;
+    constexpr int TH = 256;
+    hipLaunchKernelGGL((k_breaks<TH>), dim3(cnt, v.ntheta), dim3(TH), ((size_t)v.nseg + 1 + TH / WAVE) * 8, h->stream, v, t, h->d_brk);
+    v.brk_t0 = t;
+    h->brk_count = cnt;
+    return hipGetLastError();
 }
 static hipError_t do_resident(smc_filter_s* h, int T) {
     switch (h->model) {
@@ -205,7 +206,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     v.want_s2 = 1;
 #ifdef SMC_ABLATE
     v.abl = h_abl_tmp;
-    if (getenv("SMC_DBG") && !getenv("SMC_DBG_COUNT")) {
+    if (getenv("SMC_DBG")) {
         if (hipMalloc((void**)&v.dbg, (size_t)v.ntheta * v.nseg * 64) != hipSuccess) v.dbg = nullptr;
         else (void)hipMemset(v.dbg, 0, (size_t)v.ntheta * v.nseg * 64);
     }
@@ -241,10 +242,6 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
         TRY(hipMemsetAsync(v.x[b], 0, np * (size_t)d * 8, h->stream));
         TRY(hipMemsetAsync(v.C[b], 0, np * 8, h->stream));
     }
-    for (int b = 0; b < 2; ++b) {
-        TRY(dalloc(&v.cnt[b], ns * NCOPY));
-        TRY(hipMemsetAsync(v.cnt[b], 0, ns * NCOPY * 4, h->stream));
-    }
     if (flags & SMC_FLAG_ANCESTORS) TRY(dalloc(&v.anc, np));
     TRY(dalloc(&v.logZ, nt));
     TRY(dalloc(&v.last_logmu, nt));
@@ -270,22 +267,6 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
 #ifdef SMC_ABLATE
-    if (h->dbg_count) {
-        const size_t nwg = 1024;
-        std::vector<unsigned long long> st(nwg * 8);
-        (void)hipMemcpy(st.data(), h->dbg_count, nwg * 64, hipMemcpyDeviceToHost);
-        size_t used = 0; double ph[8] = {0}; unsigned long long t0 = ~0ull, t5 = 0;
-        for (size_t w = 0; w < nwg; ++w) {
-            if (!st[w * 8 + 5]) continue;
-            ++used;
-            if (st[w * 8] < t0) t0 = st[w * 8];
-            if (st[w * 8 + 5] > t5) t5 = st[w * 8 + 5];
-            for (int k = 1; k < 6; ++k) ph[k] += (double)(st[w * 8 + k] - st[w * 8 + k - 1]) * 0.01;
-        }
-        fprintf(stderr, "[dbg] k_count %zu WGs span %.2f us; phases(us): philox=%.2f table=%.2f draws+search+atomics=%.2f barrier=%.2f flush=%.2f\n",
-                used, (double)(t5 - t0) * 0.01, ph[1] / used, ph[2] / used, ph[3] / used, ph[4] / used, ph[5] / used);
-        (void)hipFree(h->dbg_count);
-    }
     if (h->v.dbg) {   // phase profile of the LAST k_step launch: mean over workgroups, in microseconds
         const size_t nwg = (size_t)h->v.ntheta * h->v.nseg;
         std::vector<unsigned long long> st(nwg * 8);
@@ -328,9 +309,10 @@ extern "C" int smc_destroy(smc_handle h) {
 #endif
     FilterView& v = h->v;
     for (int b = 0; b < 2; ++b) {
-        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]); (void)hipFree(v.cnt[b]);
+        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]);
     }
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->d_brk) (void)hipFree(h->d_brk);
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
@@ -361,12 +343,14 @@ extern "C" int smc_set_streams(smc_handle h, const uint32_t* s) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->d_stream, s, (size_t)h->v.ntheta * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->brk_count = 0;    // cached break points belong to the old stream ids
     return SMC_OK;
 }
 
 extern "C" int smc_reseed(smc_handle h, uint64_t seed) {
     if (!h) return fail(SMC_EINVAL, "smc_reseed: NULL handle");
     h->v.seed = seed;
+    h->brk_count = 0;    // cached break points belong to the old seed
     return SMC_OK;
 }
 
@@ -452,7 +436,7 @@ extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
     HIPCHK(hipSetDevice(h->device));
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(do_count(h, h->t, h->emitted ? 0 : 1));
+    HIPCHK(ensure_breaks(h, h->t, h->t + 64));   // step API: 64 steps of break points at a time
     const bool own = h->v.nseg == 1;
     h->v.emit_now = own ? 1 : 0;
     hipError_t le = do_step(h, h->t, h->emitted ? 0 : 1, y_t);
@@ -493,7 +477,7 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
         h->t = 1; h->inited = true; h->emitted = false;
         for (int64_t t = 1; t < T; ++t) {
             if (t == T - 1) h->v.want_s2 = 1;
-            HIPCHK(do_count(h, (uint32_t)t, 1));
+            HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
             HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
             h->cur ^= 1; h->t += 1;
         }
@@ -528,7 +512,7 @@ extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, in
     int k = 0;
     for (int64_t t = 1; t < T; ++t) {
         const bool s = k < nsample && ((t - 1) % stride) == stride / 2;
-        HIPCHK(do_count(h, (uint32_t)t, 1));
+        HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
         if (s) HIPCHK(hipEventRecord(e0[k], h->stream));
         HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
         if (s) { HIPCHK(hipEventRecord(e1[k], h->stream)); ++k; }

@@ -13,11 +13,12 @@
 // q_i = rint(p_i * 2^(48 + k_i - kb)) (uint64, exact, order independent; exp(logw_i) = p_i 2^k_i,
 // kb = max k_i) plus its record (kb, S = sum q, S2 = sum q^2 as 128 bit).  The next launch's
 // prologue turns the records of all segments of the filter into a second integer table (Dcum,
-// by shifts only) in LDS.  resample() is exactly multinomial but SEGMENT-SORTED so that a
-// workgroup's children read the same few ancestor segments (L1/L2-resident, near-streaming):
-//   k_count  draws the N iid segment picks and histograms them (integer atomics: order-free)
-//   k_step   lays the children out by segment (prefix sums of the counts) and lets child j pick
-//            iid inside its segment: search in C_b, gather x[a], propagate, weigh, normalise.
+// by shifts only) in LDS.  resample() is exactly multinomial: the n iid uniforms are generated sorted BY
+// BLOCK (block = the seg consecutive children of one workgroup) between break points that a small,
+// particle-independent kernel (k_breaks, smc_aux_kernels.h) prepares many steps ahead - so a workgroup's
+// children read the same few ancestor segments (L1/L2-resident, near-streaming) and one launch does a step:
+//   k_step   builds the table, places its children between the block's break points (iid inside),
+//            searches the segment table and C_b, gathers x[a], propagates, weighs, normalises.
 // All searches of a thread advance level by level together (2*NP independent loads in flight).
 #pragma once
 #include "smc_spec.h"
@@ -25,9 +26,6 @@
 namespace smc {
 
 constexpr int WAVE = 64;
-// The children counts are kept in NCOPY partial copies on different cache lines / channels: the
-// device-scope atomics of all workgroups otherwise serialise on 16 lines (a 4 us drain at the kernel end).
-constexpr int NCOPY = 8;
 // LDS copies of a segment's prefix sums are padded by two entries per 32: a binary search probes
 // index pos+s-1 with pos a multiple of 2s, so for s >= 32 EVERY lane's probe is = -1 (mod 32) and
 // (8-byte entries, 64 banks) lands on one bank pair -- up to 32-way conflicts.  With the pad the
@@ -54,8 +52,8 @@ struct FilterView {
     uint64_t* segS[2];
     uint64_t* segS2hi[2];
     uint64_t* segS2lo[2];
-    uint32_t* cnt[2];        // [NCOPY][ntheta][nseg] children per segment (partial counts, summed by the
-                             // reader), double-buffered by step parity
+    const uint64_t* brk;     // break points F (2^-64 fixed point) of the steps [brk_t0, ..): [step][ntheta][nseg+1]
+    uint32_t brk_t0;         //   (multi-segment multinomial resampling; smc_spec.h "break points")
     int32_t* anc;            // [ntheta][npad] or nullptr
     double* logZ;            // [ntheta]
     double* last_logmu;      // [ntheta]  (logmu, ess, K, D) of the most recently emitted weights
@@ -231,8 +229,6 @@ struct TableLds {
 __host__ __device__ inline size_t scr_words(int threads, int np) {
     return (size_t)((np + 3 > 4 ? np + 3 : 4) * (threads / WAVE) + 8);   // [red | wave totals ...]
 }
-// NOTE: every region below starts at nseg_p2*16 bytes so that k_step's two carves agree; the padded
-// Dcum (lds_pad) of k_count / k_finalize lives in a separate tail region (count_lds_bytes).
 __host__ __device__ inline size_t table_lds_bytes(int nseg_p2, int threads, int np) {
     return (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;   // sh padded to 8 B per entry
 }
@@ -249,7 +245,7 @@ __device__ __forceinline__ TableLds carve(char* smem, int nseg_p2) {
 // those weights - the return value of normalize(), particles.jl:10,12 - and adds logmu to logZ.
 template <int THREADS>
 __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur, int th, const TableLds& L, bool emit,
-                                                   bool first_emit, uint32_t t_emit, uint64_t* Dpad = nullptr) {
+                                                   bool first_emit, uint32_t t_emit) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const size_t base = (size_t)th * v.nseg;
@@ -322,7 +318,6 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
         for (int e = 0; e < E; ++e) {
             const uint64_t d = L.Dcum[tid * E + e] + excl;
             L.Dcum[tid * E + e] = d;
-            if (Dpad) Dpad[lds_pad(tid * E + e)] = d;   // bank-staggered copy for the searches
         }
     if (emit && tid == 0) {
         uint64_t Rtot = 0;
@@ -537,178 +532,15 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
             *reinterpret_cast<int2*>(v.anc + (size_t)th * v.npad + i0) = o;
         }
     }
-    if (sb == 0) {
-        for (int b = tid; b < v.nseg; b += THREADS)
-            for (int c = 0; c < NCOPY; ++c) {
-                v.cnt[0][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
-                v.cnt[1][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
-            }
-    }
     const SegRec rec = segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
     if (v.emit_now && v.nseg == 1 && tid == 0) emit_own(v, th, rec, 0u, true);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_count : level 1 of resample(weights) for multi-segment filters.  grid (ncw, ntheta).
-// Draw i in [0, n) picks segment b_i ~ Categorical(Q / Dtot) (64-bit Philox draw, integer
-// table in LDS); n_b = #{i : b_i = b} is accumulated with integer atomics, so the counts do not
-// depend on the order of arrival.  Workgroup 0 of each filter also emits (logmu, ess) of the
-// weights being resampled (the return value of the previous normalize()).
-// ---------------------------------------------------------------------------------------------
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_count(FilterView v, int cur, uint32_t t, int emit_prev) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int th = blockIdx.y, tid = threadIdx.x;
-    const TableLds L = carve(smem, v.nseg_p2);
-    unsigned int* hist = (unsigned int*)(L.scr + scr_words(THREADS, 1));   // [nseg_p2]
-    uint64_t* Dp = (uint64_t*)(hist + v.nseg_p2);                          // [lds_padded_len(nseg_p2)] padded copy of Dcum
-    for (int b = tid; b < v.nseg_p2; b += THREADS) hist[b] = 0;
-    SMC_STAMP(v, 0);
-    const uint32_t stream = v.stream[th];
-    const int64_t npairs = (v.n + 1) >> 1;
-    const int64_t per = (npairs + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = (int64_t)blockIdx.x * per, p1 = (p0 + per < npairs) ? p0 + per : npairs;
-    // first trip's Philox draws are issued before the table exists (they only need the indices)
-    uint64_t r4[4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const u32x4 rw = draw(v.seed, (uint32_t)(p0 + tid + u * THREADS), stream, t, SLOT_COUNT);
-        r4[2 * u] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
-        r4[2 * u + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
-    }
-    SMC_STAMP(v, 1);
-    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit_prev && blockIdx.x == 0, t == 1u, t - 1u, Dp);
-    SMC_STAMP(v, 2);
-    if (Dtot == 0) return;   // collapsed filter: counts stay 0, k_step falls back to identity
-    for (int64_t pb = p0; pb < p1; pb += 2 * THREADS) {
-        // two pairs (four draws) per thread per trip: independent LDS searches in flight
-        uint64_t T1[4];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int64_t p = pb + tid + u * THREADS;
-            if (pb != p0) {
-                const u32x4 rw = draw(v.seed, (uint32_t)p, stream, t, SLOT_COUNT);
-                r4[2 * u] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
-                r4[2 * u + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
-            }
-            uint64_t lo;
-            mul64wide(r4[2 * u], Dtot, T1[2 * u], lo);
-            mul64wide(r4[2 * u + 1], Dtot, T1[2 * u + 1], lo);
-            ok[2 * u] = p < p1 && 2 * p < v.n;
-            ok[2 * u + 1] = p < p1 && 2 * p + 1 < v.n;
-        }
-        // the searches carry the padded position as a byte pointer into Dp (probe offsets and step
-        // increments are workgroup-uniform scalars)
-        const char* cp[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) cp[i] = (const char*)Dp;
-        for (int s = v.nseg_p2 >> 1; s >= 1; s >>= 1) {
-            const int po = 8 * lds_probe_off(s), inc = 8 * lds_step_inc(s);
-            uint64_t val[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) val[i] = *reinterpret_cast<const uint64_t*>(cp[i] + po);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cp[i] += (val[i] <= T1[i]) ? inc : 0;
-        }
-        int pos[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pos[i] = lds_unpad((int)(cp[i] - (const char*)Dp) >> 3);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (ok[i]) atomicAdd(&hist[pos[i]], 1u);
-    }
-    SMC_STAMP(v, 3);
-    __syncthreads();
-    SMC_STAMP(v, 4);
-    unsigned int* out = v.cnt[t & 1] + ((size_t)(blockIdx.x & (NCOPY - 1)) * v.ntheta + th) * v.nseg;
-    for (int b = tid; b < v.nseg; b += THREADS) {
-        const unsigned int c = hist[b];
-        if (c) atomicAdd(&out[b], c);
-    }
-    SMC_STAMP(v, 5);
-}
-__host__ __device__ inline size_t count_lds_bytes(int nseg_p2, int threads) {
-    return table_lds_bytes(nseg_p2, threads, 1) + (size_t)nseg_p2 * 4 + (size_t)lds_padded_len(nseg_p2) * 8 + 16;
-}
-
-// Offsets prologue of k_step (multi-segment): inclusive prefix sums of the children counts and
-// the segment sums S_b into LDS.  Returns the total number of children (0 = collapsed filter).
-struct OffsLds {
-    unsigned int* off;  // [nseg_p2] inclusive sums of n_b
-    uint64_t* S;        // [nseg_p2]
-    uint64_t* scr;
-};
 // ancestor segments of C a workgroup stages in LDS (160 KiB per CU: keep >= 2 workgroups resident)
 __host__ __device__ constexpr int nstage_for(int seg) { return seg >= 8192 ? 1 : (seg >= 4096 ? 2 : 3); }
-__host__ __device__ inline size_t offs_lds_bytes(int nseg_p2, int threads, int np) {
-    return (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;
-}
 __host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int np, bool multi) {
     const size_t base = (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;
     return multi ? base + (size_t)nstage_for(2 * np * threads) * lds_padded_len(2 * np * threads) * 8 : base;
-}
-__device__ __forceinline__ OffsLds carve_offs(char* smem, int nseg_p2) {
-    OffsLds o;
-    o.S = (uint64_t*)smem;
-    o.off = (unsigned int*)(smem + (size_t)nseg_p2 * 8);
-    o.scr = (uint64_t*)(smem + (size_t)nseg_p2 * 16);
-    return o;
-}
-// `pre`: this thread's (count, S) entry was loaded early by the caller (only when nseg_p2 <= THREADS).
-// rng[0], rng[1] (LDS): the segments the children jfirst and jlast come from, i.e. the first b with
-// off[b] > j (nseg-1 if there is none).  The thread that owns that table entry writes it - no search.
-template <int THREADS>
-__device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, int cur, int th, uint32_t t, const OffsLds& L,
-                                                         bool pre, unsigned int pre_cnt, uint64_t pre_S, int* rng,
-                                                         unsigned int jfirst, unsigned int jlast) {
-    constexpr int NW = THREADS / WAVE;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const unsigned int* cn = v.cnt[t & 1] + (size_t)th * v.nseg;
-    const size_t cstride = (size_t)v.ntheta * v.nseg;   // between the NCOPY partial copies
-    const uint64_t* sS = v.segS[cur] + (size_t)th * v.nseg;
-    const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1;
-    uint64_t run = 0;
-    if (pre) {
-        run = pre_cnt;
-        if (tid < v.nseg_p2) { L.off[tid] = pre_cnt; L.S[tid] = pre_S; }
-    } else if (tid * E < v.nseg_p2) {
-        for (int e = 0; e < E; ++e) {
-            const int b = tid * E + e;
-            const bool in = b < v.nseg;
-            unsigned int cb = 0;
-            if (in)
-                for (int c = 0; c < NCOPY; ++c) cb += cn[b + c * cstride];
-            run += cb;
-            L.off[b] = (unsigned int)run;
-            L.S[b] = in ? sS[b] : 0;
-        }
-    }
-    const uint64_t incl = wave_incl_scan_u32((uint32_t)run);   // counts: the total is n < 2^31
-    uint64_t* wt = L.scr + 2 * NW;   // not the region block_max / the epilogue's first writes use
-    if (lane == WAVE - 1) wt[wave] = incl;
-    if (tid == 0) rng[0] = rng[1] = v.nseg - 1;
-    __syncthreads();
-    uint64_t off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const uint64_t x = wt[w];
-        off += (w < wave) ? x : 0;
-        tot += x;
-    }
-    const unsigned int excl = (unsigned int)(off + incl - run);
-    if (tid * E < v.nseg_p2) {
-        unsigned int below = excl;   // children before entry b
-        for (int e = 0; e < E; ++e) {
-            const unsigned int o = L.off[tid * E + e] + excl;
-            L.off[tid * E + e] = o;
-            if (below <= jfirst && jfirst < o) rng[0] = tid * E + e;
-            if (below <= jlast && jlast < o) rng[1] = tid * E + e;
-            below = o;
-        }
-    }
-    __syncthreads();
-    return (unsigned int)tot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -720,8 +552,8 @@ __device__ __forceinline__ unsigned int offsets_prologue(const FilterView& v, in
 //   normalize(logw)                -> segment epilogue into buffer `cur^1`
 // MULTI = the filter has more than one segment.
 // ---------------------------------------------------------------------------------------------
-// SYS = opt-in systematic resampling (SMC_FLAG_SYSTEMATIC): no level-1 draw, hence no k_count launch; the
-// workgroup builds the segment table itself and child j takes the point T_j = floor((j Dtot + v0) / n).
+// SYS = opt-in systematic resampling (SMC_FLAG_SYSTEMATIC): child j takes the point T_j = floor((j Dtot + v0) / n)
+// instead of the multinomial targets between the block's break points.
 template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false>
 __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_t t, int emit_prev, double yval) {
     constexpr int D = model_dim<MODEL>::value;
@@ -749,14 +581,12 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 
     // Issue-early / use-late: every load whose address is known is issued BEFORE the random-number
     // work (Philox + Box-Muller is most of this kernel's VALU), which then runs under the latency.
-    // (1) this thread's entry of the children counts and segment sums (MULTI)
-    const bool pre = MULTI && !SYS && v.nseg_p2 <= THREADS;
-    unsigned int pre_cnt = 0;
-    uint64_t pre_S = 0;
-    if (pre && tid < v.nseg) {
-#pragma unroll
-        for (int c = 0; c < NCOPY; ++c) pre_cnt += v.cnt[t & 1][((size_t)c * v.ntheta + th) * v.nseg + tid];
-        pre_S = v.segS[cur][(size_t)th * v.nseg + tid];
+    // (1) the break points of this workgroup's block of sorted uniforms (multinomial, MULTI)
+    uint64_t F0 = 0, F1 = 0;
+    if (MULTI && !SYS) {
+        const uint64_t* Fb = v.brk + ((size_t)(t - v.brk_t0) * v.ntheta + th) * ((size_t)v.nseg + 1) + sb;
+        F0 = Fb[0];
+        F1 = Fb[1];
     }
     // (2) the 64-bit pick numbers of this thread's children
     uint64_t rr[NQ];
@@ -768,19 +598,20 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         rr[2 * k] = ((uint64_t)rw.v[1] << 32) | rw.v[0];
         rr[2 * k + 1] = ((uint64_t)rw.v[3] << 32) | rw.v[2];
     }
-    // systematic: this thread's child indices relative to the workgroup's first child (masked children
-    // j >= n take the last real child's target: they are never stored as real particles)
+    // this thread's child indices relative to the workgroup's first child (masked children j >= n take
+    // the last real child's target: they are never stored as real particles)
+    const int64_t m_blk = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - seg0;   // children of this block (>= 1)
     uint32_t kk[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int64_t j = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
         kk[i] = (uint32_t)((j < v.n ? j : v.n - 1) - seg0);
     }
-    uint64_t Tsys[NQ];   // SYS: the children's targets; after the segment lookup, the in-segment thresholds
+    uint64_t Tg[NQ];   // MULTI: the children's targets in table units; after the segment lookup, the in-segment thresholds
 
-    // (3) speculative staging (NSTAGE = 3): children are segment-sorted, so the ancestors of the
-    //     children at positions [sb*SEG, (sb+1)*SEG) usually sit in segments sb-1..sb+1.  Their loads
-    //     are issued NOW, together with the counts; the range is checked once it is known (below).
+    // (3) speculative staging (NSTAGE = 3): children are sorted by block of the weight CDF, so the
+    //     ancestors of the children at positions [sb*SEG, (sb+1)*SEG) usually sit in segments
+    //     sb-1..sb+1.  Their loads are issued NOW; the range is checked once it is known (below).
     constexpr bool SPEC = MULTI && NSTAGE == 3;
     ulonglong2 stg[NSTAGE][NP];   // staging registers: NP 16-byte pieces per thread per staged segment
     int spec_lo = 0;
@@ -805,24 +636,33 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     int bseg[NQ];
     uint64_t* Cst = nullptr;   // staged segments [NSTAGE][SEG] (MULTI)
     int blo = 0;
-    if (MULTI && SYS) {
+    if (MULTI) {
         const TableLds L = carve(smem, v.nseg_p2);
         scr = L.scr;
-        // the segment table of the weights being resampled; workgroup 0 of the filter emits (logmu, ess)
-        // the step's one uniform: drawn by ONE thread (75 VALU instructions the other waves do not spend),
-        // published through LDS across the barriers of the table prologue
+        // systematic: the step's one uniform, drawn by ONE thread (75 VALU instructions the other waves do
+        // not spend) and published through LDS across the barriers of the table prologue
         uint64_t* sysw = L.scr + scr_words(THREADS, NP) - 8;   // tail words nobody else uses
-        if (tid == 0) {
+        if (SYS && tid == 0) {
             const u32x4 uw = draw(v.seed, 0u, stream, t, SLOT_SYS);
             sysw[0] = ((uint64_t)uw.v[1] << 32) | uw.v[0];
         }
+        // the segment table of the weights being resampled; workgroup 0 of the filter emits (logmu, ess)
         alive = table_prologue<THREADS>(v, cur, th, L, emit_prev && sb == 0, t == 1u, t - 1u);
         SMC_STAMP(v, 1);
-        const SysBase sbase = sys_base(alive, (uint32_t)v.n, v.inv_n, sysw[0], (uint64_t)seg0);
-        const int64_t jl = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - 1 - seg0;
-        const uint64_t Tfirst = sys_target(sbase, 0u), Tlast = sys_target(sbase, (uint32_t)(jl > 0 ? jl : 0));
-        // targets increase with j: the workgroup's ancestors are the segments [b_lo, b_hi] of its first and
-        // last child.  Usual case: both inside the speculative window - two table reads settle it.
+        // targets of the first and last child of the block, in table units.  multinomial: the block's n
+        // uniforms lie between its break points; systematic: T_j = floor((j Dtot + v0) / n)
+        SysBase sbase{};
+        uint64_t Tfirst, Tlast, lo_ = 0;
+        if (SYS) {
+            sbase = sys_base(alive, (uint32_t)v.n, v.inv_n, sysw[0], (uint64_t)seg0);
+            Tfirst = sys_target(sbase, 0u);
+            Tlast = sys_target(sbase, (uint32_t)(m_blk - 1));
+        } else {
+            mul64wide(F0, alive, Tfirst, lo_);
+            mul64wide(F1, alive, Tlast, lo_);
+        }
+        // targets lie in [Tfirst, Tlast]: the workgroup's ancestors are the segments [b_lo, b_hi] of these two.
+        // Usual case: both inside the speculative window - two table reads settle it.
         int b_lo = 0, b_hi = 0;
         const int s_hi = spec_lo + NSTAGE - 1 < v.nseg - 1 ? spec_lo + NSTAGE - 1 : v.nseg - 1;
         if (SPEC && (spec_lo == 0 || L.Dcum[spec_lo - 1] <= Tfirst) && Tlast < L.Dcum[s_hi]) {
@@ -837,63 +677,6 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             b_hi = b_hi < v.nseg ? b_hi : v.nseg - 1;
             b_hi = b_hi < b_lo ? b_lo : b_hi;
         }
-        int w0 = 1;
-        while (w0 < b_hi - b_lo + 1) w0 <<= 1;
-        Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
-        const bool spec_ok = SPEC && b_lo >= spec_lo && b_hi < spec_lo + NSTAGE;
-        int st_lo = spec_lo;
-        if (!spec_ok) {   // workgroup-uniform
-            st_lo = b_lo;
-            const int nst = (b_hi - b_lo + 1) < NSTAGE ? (b_hi - b_lo + 1) : NSTAGE;
-#pragma unroll
-            for (int sg = 0; sg < NSTAGE; ++sg) {
-#pragma unroll
-                for (int k = 0; k < NP; ++k) stg[sg][k] = ulonglong2{0, 0};
-                if (sg < nst) {
-                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(Cprev + (size_t)(b_lo + sg) * SEG);
-#pragma unroll
-                    for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
-                }
-            }
-        }
-        blo = st_lo;
-        int pos[NQ];
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            Tsys[i] = sys_target(sbase, kk[i]);
-            pos[i] = b_lo;
-        }
-        for (int s = w0 >> 1; s >= 1; s >>= 1) {
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                const int c = pos[i] + s;
-                pos[i] = (c <= b_hi && L.Dcum[c - 1] <= Tsys[i]) ? c : pos[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            bseg[i] = pos[i];
-            Sseg[i] = 0;
-            const uint64_t base = bseg[i] ? L.Dcum[bseg[i] - 1] : 0;
-            Tsys[i] = sys_threshold(Tsys[i] - base, L.sh[bseg[i]]);   // (C >> sh) > T - base  <=>  C > threshold
-        }
-    } else if (MULTI) {
-        const OffsLds L = carve_offs(smem, v.nseg_p2);
-        scr = L.scr;
-        // the children of this workgroup are consecutive, hence their segments form a range
-        // [b_lo, b_hi] (usually 1-3 segments); every child then searches only inside it
-        const unsigned int jfirst = (unsigned int)seg0;
-        const int64_t jl = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - 1;
-        const unsigned int jlast = jl > seg0 ? (unsigned int)jl : jfirst;
-        int* rng = (int*)(L.scr + scr_words(THREADS, NP) - 8);   // tail words nobody else uses
-        alive = offsets_prologue<THREADS>(v, cur, th, t, L, pre, pre_cnt, pre_S, rng, jfirst, jlast);
-        SMC_STAMP(v, 1);
-        if (sb == 0) {   // the counts of step t+1 accumulate into the other buffer: clear it
-            for (int b = tid; b < v.nseg; b += THREADS)
-                for (int c = 0; c < NCOPY; ++c) v.cnt[(t + 1) & 1][((size_t)c * v.ntheta + th) * v.nseg + b] = 0;
-        }
-        int b_lo = rng[0], b_hi = rng[1];
-        b_hi = b_hi < b_lo ? b_lo : b_hi;
         int w0 = 1;
         while (w0 < b_hi - b_lo + 1) w0 <<= 1;
         Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
@@ -917,24 +700,30 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         }
         blo = st_lo;
         int pos[NQ];
-        unsigned int jj[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            jj[i] = (unsigned int)(seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1));
+            if (SYS) {
+                Tg[i] = sys_target(sbase, kk[i]);
+            } else {   // the block's largest uniform is its break point; the others are iid below it
+                uint64_t pick;
+                mul64wide(rr[i], Tlast - Tfirst, pick, lo_);
+                Tg[i] = (int64_t)kk[i] == m_blk - 1 ? Tlast : Tfirst + pick;
+            }
             pos[i] = b_lo;
         }
         for (int s = w0 >> 1; s >= 1; s >>= 1) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const int c = pos[i] + s;
-                pos[i] = (c <= b_hi && L.off[c - 1] <= jj[i]) ? c : pos[i];
+                pos[i] = (c <= b_hi && L.Dcum[c - 1] <= Tg[i]) ? c : pos[i];
             }
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             bseg[i] = pos[i];
-            Sseg[i] = L.S[bseg[i]];
-            if (SMC_ABL(v, 5)) { bseg[i] = sb; Sseg[i] = 1ull << 50; }
+            Sseg[i] = 0;
+            const uint64_t base = bseg[i] ? L.Dcum[bseg[i] - 1] : 0;
+            Tg[i] = sys_threshold(Tg[i] - base, L.sh[bseg[i]]);   // (C >> sh) > T - base  <=>  C > threshold
         }
     } else {
         const TableLds L = carve(smem, v.nseg_p2);
@@ -949,7 +738,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             const u32x4 uw = draw(v.seed, 0u, stream, t, SLOT_SYS);
             const SysBase sbase = sys_base(Dtot, (uint32_t)v.n, v.inv_n, ((uint64_t)uw.v[1] << 32) | uw.v[0], 0u);
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) Tsys[i] = sys_threshold(sys_target(sbase, kk[i]), sh);
+            for (int i = 0; i < NQ; ++i) Tg[i] = sys_threshold(sys_target(sbase, kk[i]), sh);
             alive = Dtot;
         }
     }
@@ -974,7 +763,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         uint64_t lo;
-        if (SYS) T2[i] = Tsys[i];
+        if (SYS || MULTI) T2[i] = Tg[i];
         else mul64wide(rr[i], Sseg[i], T2[i], lo);
     }
     if (MULTI) {

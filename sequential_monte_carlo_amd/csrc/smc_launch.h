@@ -16,8 +16,6 @@ bool geo_valid(int seg, int np, Geo& g);
 
 template <int MODEL> hipError_t launch_init(const FilterView& v, Geo g, int nxt, double y, hipStream_t s);
 template <int MODEL> hipError_t launch_step(const FilterView& v, Geo g, int cur, uint32_t t, int emit_prev, double y, hipStream_t s);
-// level 1 of resample() for multi-segment filters (model independent)
-hipError_t launch_count(const FilterView& v, int cur, uint32_t t, int emit_prev, hipStream_t s);
 template <int MODEL> hipError_t launch_resident(const FilterView& v, int T, StepRec* recs, hipStream_t s);
 
 }  // namespace smc

@@ -29,6 +29,7 @@ constexpr uint32_t SLOT_NORMAL0 = 1u;    // slots 1..d: state normals
 constexpr uint32_t SLOT_OBS = 8u;        // simulate(): observation noise
 constexpr uint32_t SLOT_COUNT = 9u;      // segment pick of draw i (multi-segment filters)
 constexpr uint32_t SLOT_SYS = 10u;       // the one uniform of a systematic resampling step (opt-in)
+constexpr uint32_t SLOT_BREAK = 16u;     // block break points: 16+2i normal, 17+2i uniform, i < 8; pair = block
 
 constexpr double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
 constexpr double INV_LN2 = 0x1.71547652b82fep+0;
@@ -223,6 +224,50 @@ SMC_HD void mul64wide(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
     hi = (uint64_t)(p >> 64);
     lo = (uint64_t)p;
 #endif
+}
+
+// ---- break points of a multinomial resampling step (multi-segment filters) ------------------
+// The n iid uniforms of resample() are generated sorted BY BLOCK (block = the seg consecutive children one
+// workgroup owns): with E_i iid Exp(1) the order statistics are U_(k) = (E_1+..+E_k)/(E_1+..+E_{n+1}); a
+// block of m ranks adds a Gamma(m) variate to these sums, so the largest uniform of block w is
+// F_{w+1} = (g_0+..+g_w)/(g_0+..+g_{B-1}+e) and, given the break points, the other m-1 uniforms of the
+// block are iid on (F_w, F_{w+1}).  The break points do not depend on the particles: a small kernel
+// computes them for many steps ahead.  Everything after the Gamma variates is integer arithmetic.
+SMC_HD double uniform53(const u32x4& w) {   // (0, 1], 53 bits, from words 0 and 1
+    return (double)(((((uint64_t)w.v[1] << 32) | w.v[0]) >> 11) + 1) * TWO_M53;
+}
+// Gamma(m, 1), integer shape m >= 1, in 2^-32 fixed point (Marsaglia & Tsang 2000)
+SMC_HD uint64_t gamma_fix(uint64_t seed, uint32_t w, uint32_t stream, uint32_t t, int64_t m) {
+    const double d = (double)m - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    double G = d;   // (all 8 attempts rejected: probability ~1e-15)
+    for (uint32_t it = 0; it < 8; ++it) {
+        double x, z1;
+        box_muller(draw(seed, w, stream, t, SLOT_BREAK + 2 * it), x, z1);
+        const double vv = 1.0 + c * x;
+        if (!(vv > 0.0)) continue;
+        const double v3 = vv * vv * vv, x2 = x * x;
+        const double u = uniform53(draw(seed, w, stream, t, SLOT_BREAK + 2 * it + 1));
+        if (u < 1.0 - 0.0331 * (x2 * x2) || sp_log(u) < 0.5 * x2 + d * ((1.0 - v3) + sp_log(v3))) {
+            G = d * v3;
+            break;
+        }
+    }
+    const uint64_t g = (uint64_t)rne_pos(G * 0x1p32);
+    return g ? g : 1;
+}
+SMC_HD uint64_t exp1_fix(uint64_t seed, uint32_t w, uint32_t stream, uint32_t t) {   // Exp(1), 2^-32 fixed point, >= 1 ulp
+    const uint64_t e = (uint64_t)rne_pos(-sp_log(uniform53(draw(seed, w, stream, t, SLOT_BREAK + 1))) * 0x1p32);
+    return e ? e : 1;
+}
+// floor(P * 2^64 / S) for P < S < 2^63 (binary long division: used once per block and step, off the hot path)
+SMC_HD uint64_t div_frac64(uint64_t P, uint64_t S) {
+    uint64_t rem = P, q = 0;
+    for (int i = 0; i < 64; ++i) {
+        rem <<= 1;
+        q <<= 1;
+        if (rem >= S) { rem -= S; q |= 1; }
+    }
+    return q;
 }
 
 // ---- systematic resampling targets (opt-in; SMC_FLAG_SYSTEMATIC) ---------------------------

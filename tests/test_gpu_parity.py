@@ -338,8 +338,10 @@ def test_uneven_weights_far_segments(L, ob):
             ox, ow, oa, _ = f.state()
             assert bits([logZ[th]])[0] == bits([z])[0] and same(lm[:, th], olm) and same(es[:, th], oes)
             assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa)
-            segs = a[th] // seg
-            assert np.all(np.diff(segs) >= 0)           # children come out sorted by ancestor segment
+            # children come out sorted by BLOCK of the weight CDF (iid inside a block): no ancestor of
+            # block w+1 precedes an ancestor of block w
+            blocks = [a[th][k:k + seg] for k in range(0, n, seg)]
+            assert all(blocks[k].max() <= blocks[k + 1].min() for k in range(len(blocks) - 1))
         h.close()
 
 
