@@ -266,7 +266,12 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
     double K = k1;
     if (!one)
         for (int b = tid; b < v.nseg; b += THREADS) { const double k = sk[b]; K = k > K ? k : K; }
-    K = block_max<THREADS>(K, red);
+    {   // segment exponents are integers of magnitude < 2^30 (or -inf): reduce them as int32 (DPP max)
+        constexpr int DEADK = (int)0x80000000;
+        const int ki = K == -inf() ? DEADK : (int)K;
+        const int km = block_max_i32<THREADS>(ki, (int*)red);
+        K = km == DEADK ? -inf() : (double)km;
+    }
 
     // blocked layout: thread owns E consecutive table entries
     const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1;
