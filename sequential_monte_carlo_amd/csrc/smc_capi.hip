@@ -282,7 +282,7 @@ extern "C" int smc_destroy(smc_handle h) {
         for (size_t w = 0; w < nwg; ++w) { start_spread += (double)(st[w * 8] - t0) * 0.01; life += (double)(st[w * 8 + 7] - st[w * 8]) * 0.01; }
         fprintf(stderr, "[dbg] k_step span %.2f us; mean start offset %.2f us; mean WG life %.2f us; phases(us):", (double)(t7 - t0) * 0.01,
                 start_spread / nwg, life / nwg);
-        const char* nm[8] = {"", "offsets", "range+stage-issue+lookup", "normals", "T2+stage-write+barrier", "search", "gather+model+store", "epilogue"};
+        const char* nm[8] = {"", "table+picks", "targets+range+lookup", "normals", "T2+stage-write+barrier", "search", "gather+model+store", "epilogue"};
         for (int k = 1; k < 8; ++k) fprintf(stderr, " %s=%.2f", nm[k], ph[k] / nwg);
         fprintf(stderr, "\n");
         {   // the slowest workgroups: where do they lose time, and where do they sit (XCD = launch index % 8)

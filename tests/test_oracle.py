@@ -162,6 +162,46 @@ def test_particle_filter_pinned_by_kalman(ob):
     assert z4.var(ddof=1) < 0.6 * z.var(ddof=1)
 
 
+def test_block_sorted_resampling_is_multinomial(ob):
+    """Multi-segment resampling (uniforms generated sorted by block between Gamma break points) has the
+    multinomial law of `sample(1:n, Weights(w), n)`: chi-square of the children counts per segment over
+    many steps, and N p / N p (1-p) means and variances of the counts of arbitrary index ranges over
+    many independent draws from the SAME weights (export/import + reseed)."""
+    _, y = ob.simulate(ob.LG1D, LG, 60, 1998)
+    n, seg = 4096, 256
+    f = ob.Filter(ob.LG1D, LG, n, seg=seg, seed=5)
+    f.bootstrap_filter(y[0])
+    tot, dof = 0.0, 0
+    for t in range(1, 60):
+        _, w, _, _ = f.state()
+        f.step(y[t])
+        a = f.state()[2]
+        # ordered by block of the CDF: no ancestor of block k+1 precedes one of block k
+        blocks = [a[k:k + seg] for k in range(0, n, seg)]
+        assert all(blocks[k].max() <= blocks[k + 1].min() for k in range(len(blocks) - 1))
+        cnt = np.bincount(a // seg, minlength=n // seg)
+        p = w.reshape(-1, seg).sum(axis=1)
+        tot += float(np.sum((cnt - n * p) ** 2 / (n * p)))
+        dof += n // seg - 1
+    assert chi2.cdf(tot, dof) < 0.9995 and chi2.cdf(tot, dof) > 0.0005
+    n, seg, K = 2000, 256, 1500
+    f = ob.Filter(ob.LG1D, LG, n, seg=seg, seed=7)
+    f.bootstrap_filter(y[0])
+    snap = f.export_state()
+    _, w, _, _ = f.state()
+    cuts = [0, 100, 300, 777, 1000, 1290, 1600, 2000]
+    cnts = np.zeros((K, len(cuts) - 1))
+    for k in range(K):
+        f.import_state(snap)
+        f.reseed(1000 + k, 0)
+        f.step(y[1])
+        cnts[k] = np.histogram(f.state()[2], bins=cuts)[0]
+    p = np.array([w[cuts[i]:cuts[i + 1]].sum() for i in range(len(cuts) - 1)])
+    se_mean = np.sqrt(n * p * (1 - p) / K)
+    assert np.all(np.abs(cnts.mean(axis=0) - n * p) < 4.5 * se_mean)
+    assert np.all(np.abs(cnts.var(axis=0, ddof=1) / (n * p * (1 - p)) - 1.0) < 5 * np.sqrt(2.0 / K))
+
+
 def test_systematic_resampling_option(ob):
     """The opt-in systematic resampler of the oracle: children sorted by ancestor, every particle gets
     floor(N w) or ceil(N w) children (the defining property), and the likelihood estimate stays unbiased
