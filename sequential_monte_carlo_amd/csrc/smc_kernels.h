@@ -243,9 +243,27 @@ __device__ __forceinline__ TableLds carve(char* smem, int nseg_p2) {
 // Segment-table prologue: builds Dcum / sh in LDS from the records of filter `th` in buffer
 // `cur` (integer shifts only); returns Dtot.  If `emit`, thread 0 also produces (logmu, ess) of
 // those weights - the return value of normalize(), particles.jl:10,12 - and adds logmu to logZ.
+// this thread's record words when the table has one entry per thread (the usual case): loaded up front
+// - by table_preload, as early as the caller likes - so the workgroup pays ONE global round trip
+struct TablePre {
+    double k1;
+    uint64_t S1, hi1, lo1;
+};
+template <int THREADS>
+__device__ __forceinline__ TablePre table_preload(const FilterView& v, int cur, int th, bool emit) {
+    TablePre p{-inf(), 0, 0, 0};
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)th * v.nseg;
+    if (v.nseg_p2 <= THREADS && tid < v.nseg) {
+        p.k1 = v.segk[cur][base + tid];
+        p.S1 = v.segS[cur][base + tid];
+        if (emit) { p.hi1 = v.segS2hi[cur][base + tid]; p.lo1 = v.segS2lo[cur][base + tid]; }
+    }
+    return p;
+}
 template <int THREADS>
 __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur, int th, const TableLds& L, bool emit,
-                                                   bool first_emit, uint32_t t_emit) {
+                                                   bool first_emit, uint32_t t_emit, const TablePre* pre = nullptr) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const size_t base = (size_t)th * v.nseg;
@@ -253,16 +271,10 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
     const uint64_t* sS = v.segS[cur] + base;
     double* red = (double*)L.scr;
 
-    // one table entry per thread (the usual case): every record word is loaded up front, so the
-    // workgroup pays ONE global round trip instead of one per phase
     const bool one = v.nseg_p2 <= THREADS;
-    double k1 = -inf();
-    uint64_t S1 = 0, hi1 = 0, lo1 = 0;
-    if (one && tid < v.nseg) {
-        k1 = sk[tid];
-        S1 = sS[tid];
-        if (emit) { hi1 = v.segS2hi[cur][base + tid]; lo1 = v.segS2lo[cur][base + tid]; }
-    }
+    const TablePre pl = pre ? *pre : table_preload<THREADS>(v, cur, th, emit);
+    const double k1 = pl.k1;
+    const uint64_t S1 = pl.S1, hi1 = pl.hi1, lo1 = pl.lo1;
     double K = k1;
     if (!one)
         for (int b = tid; b < v.nseg; b += THREADS) { const double k = sk[b]; K = k > K ? k : K; }
@@ -593,6 +605,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         F0 = Fb[0];
         F1 = Fb[1];
     }
+    const TablePre tpre = MULTI ? table_preload<THREADS>(v, cur, th, emit_prev && sb == 0) : TablePre{-inf(), 0, 0, 0};
     // (2) the 64-bit pick numbers of this thread's children
     uint64_t rr[NQ];
 #pragma unroll
@@ -635,6 +648,20 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         }
     }
 
+    // ---- the state normals of this thread's children (under the loads of the records, the break points and the staged segments) ----------------
+    double z[NP][D][2];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            if (SMC_ABL(v, 2)) { z[k][c][0] = 1e-3 * (double)(pg & 1023); z[k][c][1] = -z[k][c][0]; }
+            else if (SMC_ABL(v, 6)) { const u32x4 w4 = draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c); z[k][c][0] = 1e-9 * (double)w4.v[0]; z[k][c][1] = 1e-9 * (double)w4.v[2]; }
+            else box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[k][c][0], z[k][c][1]);
+        }
+    }
+
+
     // alive = some weight is positive; otherwise the filter collapsed and ancestors are the identity
     uint64_t alive;
     uint64_t Sseg[NQ];
@@ -652,7 +679,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             sysw[0] = ((uint64_t)uw.v[1] << 32) | uw.v[0];
         }
         // the segment table of the weights being resampled; workgroup 0 of the filter emits (logmu, ess)
-        alive = table_prologue<THREADS>(v, cur, th, L, emit_prev && sb == 0, t == 1u, t - 1u);
+        alive = table_prologue<THREADS>(v, cur, th, L, emit_prev && sb == 0, t == 1u, t - 1u, &tpre);
         SMC_STAMP(v, 1);
         // targets of the first and last child of the block, in table units.  multinomial: the block's n
         // uniforms lie between its break points; systematic: T_j = floor((j Dtot + v0) / n)
@@ -749,19 +776,6 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     }
 
     SMC_STAMP(v, 2);
-    // ---- the state normals of this thread's children (under the staging loads) ----------------
-    double z[NP][D][2];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            if (SMC_ABL(v, 2)) { z[k][c][0] = 1e-3 * (double)(pg & 1023); z[k][c][1] = -z[k][c][0]; }
-            else if (SMC_ABL(v, 6)) { const u32x4 w4 = draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c); z[k][c][0] = 1e-9 * (double)w4.v[0]; z[k][c][1] = 1e-9 * (double)w4.v[2]; }
-            else box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[k][c][0], z[k][c][1]);
-        }
-    }
-
     SMC_STAMP(v, 3);
     // ---- a = resample(weights), level 2: iid pick inside the child's segment -------------------
     uint64_t T2[NQ];
