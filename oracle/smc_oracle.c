@@ -35,12 +35,13 @@
  *     are carried as fixed point q_i = rint(p_i * 2^(48 + k_i - kb)), so every sum and prefix
  *     sum is an exact integer and independent of the order a parallel machine adds in.
  *   - segments are combined by integer shifts (2^(K - kb), K = max kb) into a second table.
- *     resample (particles.jl:17-19) is the multinomial law of StatsBase.sample(1:n, Weights(w), n),
- *     drawn in two levels: N iid segment picks are COUNTED (n_b children for segment b), the
- *     children are laid out sorted by segment, and child j picks its ancestor iid inside its
- *     segment.  The joint law of the ancestor multiset is exactly Multinomial(N, w); only the
- *     (unobservable, exchangeable) order of the children differs from an unsorted draw.  The
- *     stand-alone resample(w, N) keeps the unsorted iid order of the reference.
+ *     resample (particles.jl:17-19) is the multinomial law of StatsBase.sample(1:n, Weights(w), n):
+ *     n iid uniforms through the inverse of the integer weight CDF.  With several segments the
+ *     uniforms are generated sorted BY BLOCK (block = seg consecutive children) between break
+ *     points built from Gamma variates (resample_breaks below); inside a block the order is iid.
+ *     The joint law of the ancestors is exactly Multinomial(n, w); only the (unobservable,
+ *     exchangeable) order of the children differs from an unsorted draw.  The stand-alone
+ *     resample(w, N) keeps the unsorted iid order of the reference.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off; never -ffast-math).
  */

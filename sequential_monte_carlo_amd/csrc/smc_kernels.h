@@ -499,7 +499,7 @@ __device__ __forceinline__ double nan_mask() { return bits2d(0x7ff8000000000000U
 // XCD-aware block -> segment map (speed only, never correctness): workgroups are dealt round-robin
 // over the 8 XCDs, so blocks with equal blockIdx.x % 8 share an L2.  Give each XCD a CONTIGUOUS
 // range of segments: the workgroup that wrote segment b at step t-1 and the workgroups that read
-// segments b-1..b+1 at step t (children are segment-sorted) then sit on the same XCD, and the
+// segments b-1..b+1 at step t (children are ordered by block of the weight CDF) then sit on the same XCD, and the
 // staging loads / gathers hit that XCD's 4 MiB L2 instead of going out to the Infinity Cache.
 __device__ __forceinline__ int logical_segment(int bid, int nseg) {
     return (nseg & 7) ? bid : (bid & 7) * (nseg >> 3) + (bid >> 3);
