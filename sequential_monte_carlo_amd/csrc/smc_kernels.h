@@ -658,6 +658,9 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             if (SMC_ABL(v, 2)) { z[k][c][0] = 1e-3 * (double)(pg & 1023); z[k][c][1] = -z[k][c][0]; }
             else if (SMC_ABL(v, 6)) { const u32x4 w4 = draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c); z[k][c][0] = 1e-9 * (double)w4.v[0]; z[k][c][1] = 1e-9 * (double)w4.v[2]; }
             else box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[k][c][0], z[k][c][1]);
+            // systematic: keep the normals HERE, under the load latencies.  multinomial: measured faster when the
+            // compiler sinks them next to their use, where they fill the waits of the LDS search
+            if (SYS) asm volatile("" : "+v"(z[k][c][0]), "+v"(z[k][c][1]));
         }
     }
 
