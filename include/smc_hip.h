@@ -40,8 +40,7 @@ extern "C" {
 #define SMC_FLAG_SYSTEMATIC 4u /* OPT-IN: systematic resampling instead of the reference's multinomial
                                 * resample (particles.jl:17-19 draws iid): one uniform per step, child j takes
                                 * the point (j + u)/N of the weight CDF.  Same expectation N w_i of every
-                                * particle's children, lower variance, a different law - never the default.
-                                * Multi-segment filters then need no level-1 draw (one launch per step).   */
+                                * particle's children, lower variance, a different law - never the default. */
 
 typedef struct smc_filter_s* smc_handle;
 
