@@ -135,6 +135,22 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t wave_sum(uint64_t v) { return readlane_u64(wave_incl_scan(v, 0), WAVE - 1); }
+// Combine the NW (<= 16) per-wave totals tot[0..NW) in LDS: off = sum of the totals of the waves before
+// this one, all = their sum.  Lane w reads tot[w], a DPP scan inside the first row of 16 lanes, two lane
+// reads - instead of a loop over NW with selects in every thread.  `wave` must be wave-uniform.
+template <int NW>
+__device__ __forceinline__ void wave_totals(const uint64_t* tot, int lane, int wave, uint64_t& off, uint64_t& all) {
+    static_assert(NW >= 1 && NW <= 16 && (NW & (NW - 1)) == 0, "wave count");
+    uint64_t t = tot[lane & (NW - 1)];
+    if (NW > 1) t += dpp_u64z<0x111, 0xf>(t);
+    if (NW > 2) t += dpp_u64z<0x112, 0xf>(t);
+    if (NW > 4) t += dpp_u64z<0x114, 0xf>(t);
+    if (NW > 8) t += dpp_u64z<0x118, 0xf>(t);
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
+    all = readlane_u64(t, NW - 1);
+    const uint64_t prev = readlane_u64(t, ws > 0 ? ws - 1 : 0);
+    off = ws > 0 ? prev : 0;
+}
 
 // 128-bit unsigned accumulator (sum of q^2).  NOTE: do not "optimise" this into 24-bit limb
 // products: hipcc 7.2 folds (q & 0xFFFFFF)^2 accumulations into v_mad_u64_u32 on the UNMASKED
@@ -323,13 +339,8 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
         if (lane == 0) wr[wave] = rw;
     }
     __syncthreads();
-    uint64_t off = 0, Dtot = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        const uint64_t t = wt[w];
-        off += (w < wave) ? t : 0;
-        Dtot += t;
-    }
+    uint64_t off, Dtot;
+    wave_totals<NW>(wt, lane, wave, off, Dtot);
     const uint64_t excl = off + incl - run;
     if (tid * E < v.nseg_p2)
         for (int e = 0; e < E; ++e) {
@@ -428,13 +439,8 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     uint64_t basek = 0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        uint64_t off = 0, ktot = 0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const uint64_t t = wtot[k * NW + w];
-            off += (w < wave) ? t : 0;
-            ktot += t;
-        }
+        uint64_t off, ktot;
+        wave_totals<NW>(wtot + k * NW, lane, wave, off, ktot);
         const uint64_t excl = basek + off + incl[k] - ps[k];
         ulonglong2 cc;
         cc.x = excl + q[k][0];
