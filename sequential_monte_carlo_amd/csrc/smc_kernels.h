@@ -99,7 +99,14 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint64_t dpp_u64z(uint64_t v) {   // lanes without a source read 0
-    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)v), hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+    uint32_t lo, hi;
+    if (ROW_MASK == 0xf) {   // every row enabled: bound_ctrl supplies the zeros, no "old" register to clear
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true);
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
+    } else {
+        lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)v);
+        hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+    }
     return ((uint64_t)hi << 32) | lo;
 }
 // inclusive prefix sum over the 64 lanes of a wave
