@@ -46,6 +46,8 @@ struct smc_filter_s {
     double* d_wdense = nullptr;
     StepRec* d_recs = nullptr;
     double* h_pin = nullptr;                   // pinned host mirror [3][ntheta]: logZ | last_logmu | last_ess
+    uint64_t* d_q = nullptr;                   // scratch of smc_get_quantiles (histograms, select state)
+    size_t qcap = 0;
     uint64_t* d_brk = nullptr;                 // break points of the steps [v.brk_t0, v.brk_t0 + brk_count)
     uint32_t brk_cap = 0, brk_count = 0;
     int64_t reccap = 0;
@@ -313,6 +315,7 @@ extern "C" int smc_destroy(smc_handle h) {
     }
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->d_brk) (void)hipFree(h->d_brk);
+    if (h->d_q) (void)hipFree(h->d_q);
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
@@ -826,8 +829,12 @@ extern "C" int smc_get_quantiles(smc_handle h, int component, const double* p, i
     const size_t nth = (size_t)h->v.ntheta, nst = nth * np;
     // scratch: hist [ntheta][np][256] u64 | state [ntheta][np] | P64 [np] | out [ntheta][np]
     const size_t words = nst * 256 + nst * 3 + QMAX + nst;
-    uint64_t* buf = nullptr;
-    HIPCHK(hipMalloc((void**)&buf, words * 8));
+    if (words > h->qcap) {   // scratch kept with the handle: the README loop asks for quantiles every step
+        if (h->d_q) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_q); h->d_q = nullptr; h->qcap = 0; }
+        HIPCHK(hipMalloc((void**)&h->d_q, words * 8));
+        h->qcap = words;
+    }
+    uint64_t* buf = h->d_q;
     unsigned long long* hist = (unsigned long long*)buf;
     QState* st = (QState*)(buf + nst * 256);
     uint64_t* P64 = buf + nst * 256 + nst * 3;
@@ -845,7 +852,6 @@ extern "C" int smc_get_quantiles(smc_handle h, int component, const double* p, i
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, nst * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(buf);
     if (e != hipSuccess) return fail(SMC_EHIP, hipGetErrorString(e));
     return SMC_OK;
 }
