@@ -492,8 +492,10 @@ def test_time_step_kernel_runs(L):
 def test_randomized_configurations(L, ob):
     """Fuzz: random model family / parameters / Nx / seg / n_theta / T / seed / streams, resident or
     not -- every one bit-exact against the oracle (logZ, traces, states, weights, ancestors)."""
+    import os
+    iters = int(os.environ.get("SMC_FUZZ_ITERS", "40"))           # more on demand (same seeds first)
     rng = np.random.default_rng(20260401)
-    for it in range(40):
+    for it in range(iters):
         model = int(rng.integers(1, 4))
         seg = int(rng.choice([0, 256, 512, 1024, 2048]))
         n = int(rng.integers(1, 9000))
@@ -503,6 +505,11 @@ def test_randomized_configurations(L, ob):
         T = int(rng.integers(1, 9))
         seed = int(rng.integers(1, 2**62))
         flags = L.FLAG_ANCESTORS | (L.FLAG_NO_RESIDENT if rng.random() < 0.5 else 0)
+        systematic = it >= 40 and rng.random() < 0.35           # (iterations 0..39 keep their original draws)
+        if it >= 40 and rng.random() < 0.15:
+            n = int(rng.integers(9000, 90000))
+        if systematic:
+            flags |= L.FLAG_SYSTEMATIC
         if model == 1:
             raws = np.column_stack([rng.uniform(-1, 1, nth), rng.uniform(0.5, 2, nth), rng.lognormal(0, 1, nth),
                                     rng.lognormal(-1, 1.5, nth), rng.normal(0, 2, nth), rng.lognormal(0, 1, nth)])
@@ -522,10 +529,10 @@ def test_randomized_configurations(L, ob):
         logZ, lm, es = h.log_likelihood(y, trace=True)
         x, w, a = h.state()
         for th in range(nth):
-            f = ob.Filter(model, raws[th], n, seg=seg, seed=seed, stream=int(streams[th]))
+            f = ob.Filter(model, raws[th], n, seg=seg, seed=seed, stream=int(streams[th]), systematic=systematic)
             z, olm, oes = f.log_likelihood(y, trace=True)
             ox, ow, oa, _ = f.state()
-            ctx = (it, model, n, seg, nth, T, th)
+            ctx = (it, model, n, seg, nth, T, th, systematic)
             assert bits([logZ[th]])[0] == bits([z])[0], ctx
             assert same(lm[:, th], olm) and same(es[:, th], oes), ctx
             assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa), ctx
