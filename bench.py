@@ -147,7 +147,8 @@ def main():
             units = float(nth) * nx * T
             kname = "k_resident"
         else:
-            avg_ms, min_ms = h.time_step_kernel(y[: min(T, 400)], nsample=64)
+            # HIP-event brackets around runs of 8 consecutive k_step launches, averaged per launch
+            avg_ms, min_ms = h.time_step_kernel(y[: min(T, 600)], nsample=64)
             ovh = h.event_overhead_ms(64)          # what an empty event bracket reads (reported, NOT subtracted)
             ms = avg_ms
             units = float(nth) * nx
@@ -174,7 +175,8 @@ def main():
         if valu:
             roof["secondary"] = valu       # the HBM model is SURVEY's accounting; the kernel's real ceiling is the ALU
         if not h.resident:
-            roof["empty_event_bracket_ms"] = round(ovh, 6)   # rocprofv3's kernel-only average is ~2 us below launch_ms
+            roof["empty_event_bracket_ms"] = round(ovh, 6)   # an event pair's own cost, spread over the 8 launches of a bracket
+            roof["launches_per_bracket"] = 8
 
     # ---- CPU baseline: the oracle (scalar port of particles.jl), bounded sample -----------------
     cpu = None
