@@ -249,7 +249,20 @@ def test_full_size_c2_properties(L):
     x, w, a = h.state()
     assert abs(w.sum() - 1.0) < 1e-10 and w.min() >= 0
     assert a.min() >= 0 and a.max() < n and len(np.unique(a)) > 0.4 * n
-    assert np.any(np.diff(a[0].astype(np.int64)) < 0)                   # unsorted iid multinomial
+    assert np.any(np.diff(a[0].astype(np.int64)) < 0)                   # iid inside a block: not globally sorted
+    # the resampling law at full size: one more step from these weights; children counts per ancestor segment
+    # against N p (chi-square, 511 dof), and the children ordered by block of the weight CDF
+    from scipy.stats import chi2
+    w_prev = w[0].copy()
+    h.step(0.3)
+    a2 = h.state(want_w=False)[2][0].astype(np.int64)
+    seg = h.seg
+    cnt = np.bincount(a2 // seg, minlength=n // seg).astype(np.float64)
+    p = w_prev.reshape(-1, seg).sum(axis=1)
+    stat = float(np.sum((cnt - n * p) ** 2 / (n * p)))
+    assert 0.0005 < chi2.cdf(stat, n // seg - 1) < 0.9995, stat
+    blocks = a2.reshape(-1, seg)
+    assert np.all(blocks[:-1].max(axis=1) <= blocks[1:].min(axis=1))
     # filtered mean against the Kalman filtered mean
     from_pf = float(np.sum(w[0] * x[0, 0]))
     A, B, Q, R = LG[:4]
@@ -260,7 +273,7 @@ def test_full_size_c2_properties(L):
         s = B * B * S + R
         xm, S = xm + S * B / s * (yt - B * xm), S - (S * B) ** 2 / s
     assert abs(from_pf - xm) < 6 * np.sqrt(S / n) + 1e-3
-    assert same(h.log_likelihood(y), logZ)                              # deterministic replay
+    assert same(h.log_likelihood(y), logZ)                              # deterministic replay (also after the extra step)
     h.reseed(2)
     assert h.log_likelihood(y)[0] != logZ[0]
     h.close()
