@@ -570,7 +570,8 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
 __host__ __device__ constexpr int nstage_for(int seg) { return seg >= 8192 ? 1 : (seg >= 4096 ? 2 : 3); }
 __host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int np, bool multi) {
     const size_t base = (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;
-    return multi ? base + (size_t)nstage_for(2 * np * threads) * lds_padded_len(2 * np * threads) * 8 : base;
+    // single-segment filters stage their one segment too (the search then probes LDS, not global memory)
+    return base + (size_t)(multi ? nstage_for(2 * np * threads) : 1) * lds_padded_len(2 * np * threads) * 8;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -659,6 +660,12 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
                 for (int k = 0; k < NP; ++k) stg[sg][k] = src[tid + k * THREADS];
             }
         }
+    }
+
+    ulonglong2 stg1[NP];   // single segment: the filter's whole C, staged like a multi-segment window of one
+    if (!MULTI) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) stg1[k] = reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS];
     }
 
     // ---- the state normals of this thread's children (under the loads of the records, the break points and the staged segments) ----------------
@@ -808,6 +815,11 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             for (int k = 0; k < NP; ++k)
                 *reinterpret_cast<ulonglong2*>(Cst + sg * SEGP + lds_pad(2 * (tid + k * THREADS))) = stg[sg][k];
         __syncthreads();   // staged segments visible
+    } else {
+        Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) *reinterpret_cast<ulonglong2*>(Cst + lds_pad(2 * (tid + k * THREADS))) = stg1[k];
+        __syncthreads();
     }
     SMC_STAMP(v, 4);
     int pos[NQ];
@@ -853,14 +865,19 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             }
         }
     } else {
+        const char* pb[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) pb[i] = (const char*)Cst;
 #pragma unroll
         for (int s = SEG >> 1; s >= 1; s >>= 1) {
             uint64_t val[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) val[i] = Cprev[pos[i] + s - 1];
+            for (int i = 0; i < NQ; ++i) val[i] = *reinterpret_cast<const uint64_t*>(pb[i] + 8 * lds_probe_off(s));
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) pos[i] += (val[i] <= T2[i]) ? s : 0;
+            for (int i = 0; i < NQ; ++i) pb[i] += (val[i] <= T2[i]) ? 8 * lds_step_inc(s) : 0;
         }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) pos[i] = lds_unpad((int)(pb[i] - (const char*)Cst) >> 3);
     }
     SMC_STAMP(v, 5);
     int64_t anc[NQ];

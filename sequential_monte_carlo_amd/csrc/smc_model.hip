@@ -19,12 +19,15 @@ template <int THREADS, int NP, bool SYS>
 static hipError_t step_sys_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
     const size_t lds = step_lds_bytes(v.nseg_p2, THREADS, NP, v.nseg > 1);
     if (lds > 64 * 1024) {
-        static bool raised = false;   // per instantiation
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, true, SYS>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static bool raised[2] = {false, false};   // per instantiation
+        const int m = v.nseg > 1 ? 1 : 0;
+        if (!raised[m]) {
+            hipError_t e = m ? hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, true, SYS>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                             : hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, false, SYS>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            raised = true;
+            raised[m] = true;
         }
     }
     if (v.nseg > 1)
