@@ -1,16 +1,8 @@
-# INTEGRATION — binding `libsmchip.so` into SequentialMonteCarlo.jl
-
-The reference has no FFI; its filters are generic over `StateSpaceModel` and call the model methods
-per particle (`src/particles.jl:97-98,123-124`). The drop-in keeps every generic function and adds
-**more specific methods** for the model types the GPU path implements; any other model type keeps
-falling through to the reference's own CPU code. Nothing in `src/` has to be edited except adding
-one `include("hip_backend.jl")` after `include("particles.jl")`.
-
-Julia is not available in the build image, so the stub below (also kept as `julia/hip_backend.jl`) is *unexecuted* here; it is mechanical
-(one `ccall` per entry point of `include/smc_hip.h`) and mirrors `sequential_monte_carlo_amd/_lib.py`
-and `particles.py`, which are the tested bindings of the same library.
-
-```julia
+# hip_backend.jl -- methods of SequentialMonteCarlo.jl's own generic functions over libsmchip.so
+# (include/smc_hip.h).  UNEXECUTED in the build image (no Julia there); mechanical: one ccall per entry
+# point, mirroring the tested Python binding sequential_monte_carlo_amd/_lib.py + particles.py.
+# Usage: add `include("hip_backend.jl")` after `include("particles.jl")` in src/SequentialMonteCarlo.jl
+# (INTEGRATION.md explains the boundary).
 # src/hip_backend.jl  -- methods of the reference's own generic functions over libsmchip.so
 const LIBSMC = "libsmchip"            # sequential_monte_carlo_amd/lib/libsmchip.so on LD_LIBRARY_PATH
 
@@ -116,37 +108,3 @@ function resample(w::Vector{Float64}, N::Int64, ::Val{:hip}; seed=rand(UInt64))
         (Ptr{Float64}, Int64, Int64, UInt64, UInt32, UInt32, Ptr{Int32}, Cint), w, length(w), N, seed, 0, 0, a, 0))
     return Int.(a) .+ 1            # the C ABI is 0-based
 end
-```
-
-Sampler side (`src/smc_samplers.jl`): replace the three threaded loops by the batched method, e.g.
-`:223-229` becomes `smc.logZ .= log_likelihood(smc.N, y, smc.model.(smc.θ))`; `resample!` (`:74-84`)
-calls `smc_permute`; the accept branch of `rejuvenate!` (`:130-133`) calls `smc_copy_from(main, prop,
-mask)`. `sequential_monte_carlo_amd/smc_samplers.py` is that restructuring, tested against the
-oracle backend bit for bit.
-
-Other entry points a maintainer would bind the same way (all in `include/smc_hip.h`, all exercised by the
-Python binding `_lib.py`): `smc_permute` (`resample!`, one GPU), `smc_copy_from` (PMMH accept),
-`smc_pack_slots` / `smc_unpack_slots` (move whole filters through a device buffer when θ is sharded over GPUs:
-pack → RCCL all-to-all → unpack), `smc_get_moments` / `smc_get_quantiles` (filtered mean/variance and weighted quantiles on the device, for the
-README's per-step summaries and `examples/inflation_example.jl:45`), `smc_kalman_log_likelihood` (the exact scalar Kalman `log_likelihood(y, model)` of
-`src/kalman_filter.jl:55-70`, batched over parameter rows — the IBIS sampler's inner filter), `smc_simulate`
-(`simulate`, host code), `smc_set_streams` / `smc_reseed` (random-number contract).
-
-## Contract summary (from `include/smc_hip.h`)
-
-| aspect | rule |
-|---|---|
-| ownership | host arrays are caller-owned and borrowed for the call (`GC.@preserve`); device state is owned by the handle and freed by `smc_destroy` (Julia `finalizer`) |
-| errors | every entry point returns `0` or a negative `SMC_E*`; message via thread-local `smc_last_error()`; the library never aborts and never falls back to a CPU path |
-| indices | 0-based `int32` in C; the wrapper adds 1 |
-| layouts | params `[n_theta][n_raw]`; `x [d][n_theta][n_x]`; `w`, `anc` `[n_theta][n_x]` |
-| threading | one host thread per handle at a time; handles are independent (one HIP stream each) |
-| randomness | Philox4x32-10 keyed by `(seed, stream=global theta index, t, particle pair, slot)`; identical results on any number of GPUs |
-| options | `flags` of `smc_create`: `SMC_FLAG_ANCESTORS` (keep `a`), `SMC_FLAG_NO_RESIDENT` (testing), `SMC_FLAG_SYSTEMATIC` (opt-in systematic resampling: not the reference's law, 1.4× faster on a 2²⁰-particle filter) |
-| deviations from the reference, on purpose | value-copy semantics in `resample!` (the reference aliases `x[m]`, SURVEY app. A.4); `bootstrap_filter!` returns new weights like the reference (`w` not mutated); children of a resampling step of a filter with more than 8192 particles come out ordered by block of the weight CDF (same multinomial law; the order of children is not observable) |
-
-## Build
-
-`python -c "import __graft_entry__ as g; g.build()"` → `hipcc --offload-arch=gfx950` via
-`sequential_monte_carlo_amd/csrc/Makefile` (`make -j4`), output
-`sequential_monte_carlo_amd/lib/libsmchip.so` (in-tree). Links only `libamdhip64`.
