@@ -663,7 +663,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     }
 
     ulonglong2 stg1[NP];   // single segment: the filter's whole C, staged like a multi-segment window of one
-    if (!MULTI) {
+    constexpr bool EARLY1 = D == 1;   // (with three state coordinates the early copy only spills to scratch)
+    if (!MULTI && EARLY1) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) stg1[k] = reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS];
     }
@@ -818,7 +819,10 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     } else {
         Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
 #pragma unroll
-        for (int k = 0; k < NP; ++k) *reinterpret_cast<ulonglong2*>(Cst + lds_pad(2 * (tid + k * THREADS))) = stg1[k];
+        for (int k = 0; k < NP; ++k) {
+            if (!EARLY1) stg1[k] = reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS];
+            *reinterpret_cast<ulonglong2*>(Cst + lds_pad(2 * (tid + k * THREADS))) = stg1[k];
+        }
         __syncthreads();
     }
     SMC_STAMP(v, 4);
