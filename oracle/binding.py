@@ -51,6 +51,8 @@ def lib():
         L.orc_filter_create.argtypes = [C.c_int, _dp, C.c_int64, C.c_int, C.c_uint64, C.c_uint32]
         L.orc_filter_destroy.argtypes = [C.c_void_p]
         L.orc_filter_reseed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.orc_filter_set_rng.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.orc_filter_set_rng.restype = None
         L.orc_filter_set_params.argtypes = [C.c_void_p, _dp]
         L.orc_filter_copy_state.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_filter_state_words.restype = C.c_int64
@@ -175,6 +177,10 @@ class Filter:
 
     def reseed(self, seed, stream=0):
         lib().orc_filter_reseed(self._h, seed, stream)
+
+    def set_rng(self, seed, stream):
+        """new Philox key / stream id without restarting the series (smc_reseed / smc_set_streams mid-run)"""
+        lib().orc_filter_set_rng(self._h, seed, stream)
 
     def set_params(self, raw):
         raw = np.ascontiguousarray(raw, dtype=np.float64)

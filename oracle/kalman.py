@@ -10,7 +10,7 @@ Kalman step  src/kalman_filter.jl:29-53  and its whole-series loop  :55-70 :
 
 Q, R and sigma0 are variances (src/state_space_models.jl:93,102,108).
 NOTE the reference starts the recursion from (x0, sigma0) and *predicts before the first
-update* (:185-187 are executed for t = 1 too), so y[1] is scored against N(B A x0, B^2(A^2 sigma0+Q)+R),
+update* (kalman_filter.jl:39-40 are executed for t = 1 too), so y[1] is scored against N(B A x0, B^2(A^2 sigma0+Q)+R),
 whereas bootstrap_filter draws x_1 ~ N(x0, sigma0) directly (particles.jl:97).  The two agree
 iff the Kalman recursion is started one step earlier; `log_likelihood(..., predict_first=False)`
 is the variant consistent with the particle filter and is the one used as the pin.

@@ -19,8 +19,8 @@
  * un-vendored, un-pinned Distributions.jl / StatsBase.jl / Random (Project.toml:6-13), with
  * no tests or golden vectors: bit-level parity with Julia is unpinned by construction.
  * This oracle is pinned instead by the reference's own exact Kalman log-likelihood
- * (src/kalman_filter.jl:29-70, restated in oracle/kalman.py): tests/test_oracle_kalman.py
- * checks E[exp(logZ_PF - logZ_KF)] = 1 and mean(logZ_PF) - logZ_KF within MC error.
+ * (src/kalman_filter.jl:29-70, restated in oracle/kalman.py): tests/test_oracle.py
+ * (test_particle_filter_pinned_by_kalman) checks E[exp(logZ_PF - logZ_KF)] = 1 and mean(logZ_PF) - logZ_KF within MC error.
  *
  * Because the reference's random stream cannot be reproduced, the *specification* of the
  * stream and of every rounding step is defined here (DESIGN.md "Numerical specification")
@@ -744,6 +744,8 @@ void orc_filter_import(orc_filter* f, const uint64_t* b) {
 }
 
 void orc_filter_reseed(orc_filter* f, uint64_t seed, uint32_t stream) { f->seed = seed; f->stream = stream; f->t = 0; }
+/* smc_reseed / smc_set_streams in the middle of a series: new Philox key / stream id, the time index goes on */
+void orc_filter_set_rng(orc_filter* f, uint64_t seed, uint32_t stream) { f->seed = seed; f->stream = stream; }
 
 /* bootstrap_filter(N, y, model)  particles.jl:87-105  -> logmu */
 double orc_bootstrap_filter(orc_filter* f, double y) {
@@ -848,12 +850,12 @@ void orc_kalman_log_likelihood(const double* raw, const double* y, int64_t T, in
     const double A = raw[0], B = raw[1], Q = raw[2], R = raw[3];
     double x = raw[4], S = raw[5], logZ = 0.0;
     for (int64_t t = 0; t < T; ++t) {
-        if (predict_first || t > 0) { x = A * x; S = (A * A) * S + Q; }           /* :186-187 */
-        const double s = (B * B) * S + R, dy = y[t] - B * x;                      /* :189-190 */
+        if (predict_first || t > 0) { x = A * x; S = (A * A) * S + Q; }           /* kalman_filter.jl:39-40 */
+        const double s = (B * B) * S + R, dy = y[t] - B * x;                      /* :42-43 */
         const double K = S * B, inv = 1.0 / s;
-        x = x + (K * inv) * dy;                                                   /* :193 */
-        S = S - (K * K) * inv;                                                    /* :194 */
-        logZ += -0.5 * (LOG2PI + orc_log(s) + (dy / s) * dy);                     /* :197-199 */
+        x = x + (K * inv) * dy;                                                   /* :46 */
+        S = S - (K * K) * inv;                                                    /* :47 */
+        logZ += -0.5 * (LOG2PI + orc_log(s) + (dy / s) * dy);                     /* :50-52 */
     }
     out[0] = x; out[1] = S; out[2] = logZ;
 }

@@ -87,6 +87,51 @@ def test_density_tempered_hip_equals_oracle_backend():
     assert np.array_equal(bits(sh.omega), bits(so.omega)) and sh.psteps == so.psteps
 
 
+def ucsv_mod(theta):
+    """examples/inflation_example.jl:227-230: UCSV(θ[1], θ[2], (θ[3], θ[4])) with γε = γη = θ[1]"""
+    return smc.UCSV((theta[0], theta[0]), theta[1], (theta[2], theta[3]))
+
+
+def ucsv_prior():
+    """examples/inflation_example.jl:232-237"""
+    return smc.product_distribution([smc.Uniform(0.0, 1.0), smc.Normal(3.0, 2.0), smc.Uniform(0.0, 2.0), smc.Uniform(0.0, 2.0)])
+
+
+def _run_ucsv(backend, online=False):
+    u = smc.UCSV((0.2, 0.2), 3.0, (0.0, 0.0))
+    _, y = smc.simulate(u, 20, seed=1998)
+    s = smc.SMC(256, 24, ucsv_mod, ucsv_prior(), 2, 0.7 if online else 0.5, seed=3, backend=backend)
+    buf = io.StringIO()
+    if online:
+        smc.smc2(s, y)
+        for t in range(2, 21):
+            smc.smc2_step(s, y, t, verbose=True, out=buf)
+        x, w, _ = s._main.state()
+        return s, buf.getvalue(), x, w
+    stages = smc.density_tempered(s, y, verbose=True, out=buf)
+    return s, buf.getvalue(), stages, None
+
+
+def test_density_tempered_ucsv_hip_equals_oracle_backend():
+    """BASELINE configs[4] at a size the oracle finishes in seconds: density_tempered (smc_samplers.jl:222-281)
+    over the UCSV model with the example's prior U(0,1) x N(3,2) x U(0,2) x U(0,2); every proposal outside the
+    prior's support is skipped like the reference does (:116)."""
+    sh, th, stg_h, _ = _run_ucsv(smc.smc_samplers.HipBackend())
+    so, to, stg_o, _ = _run_ucsv(OracleBackend())
+    assert th == to and stg_h == stg_o and len(stg_h) >= 2
+    assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+    assert np.array_equal(bits(sh.omega), bits(so.omega)) and sh.psteps == so.psteps
+    assert np.all(sh.theta[:, 0] > 0) and np.all(sh.theta[:, 0] < 1)          # never left the prior's support
+
+
+def test_smc2_online_ucsv_hip_equals_oracle_backend():
+    sh, th, xh, wh = _run_ucsv(smc.smc_samplers.HipBackend(), online=True)
+    so, to, xo, wo = _run_ucsv(OracleBackend(), online=True)
+    assert th == to and "[rejuvenating]" in th
+    assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+    assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo))
+
+
 def test_samplers_with_systematic_resampling_option():
     """HipBackend(resampler="systematic") == the oracle backend with its systematic resampler, whole runs."""
     for online in (False, True):

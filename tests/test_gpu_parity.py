@@ -280,19 +280,107 @@ def test_full_size_c2_properties(L):
 
 
 def test_full_size_c3_sv_properties(L):
-    """C3: stochastic volatility, Nx = 2^20 (T shortened to 300 of 5000 to bound test time)."""
-    n, T = 1 << 20, 300
+    """C3 at its real size: stochastic volatility, Nx = 2^20, T = 5000 (BASELINE configs[2]).  The series
+    crosses the 1024-step break-point window of log_likelihood four times and the 64-step window of the
+    step API 78 times; both walks must give the same bits (particles.jl:141-144: logZ = sum of logmu_t)."""
+    n, T = 1 << 20, 5000
     _, y = L.simulate(2, SV, T, 1998)
-    h = L.Handle(2, 1, n, seed=1)
+    h = L.Handle(2, 1, n, seed=1, flags=L.FLAG_ANCESTORS)
     h.set_params(SV)
     logZ, lm, es = h.log_likelihood(y, trace=True)
-    assert np.isfinite(logZ[0]) and np.all(es >= 1.0) and np.all(es <= n)
+    assert np.isfinite(logZ[0]) and np.all(np.isfinite(lm)) and np.all(es >= 1.0) and np.all(es <= n)
+    assert es.mean() > 0.3 * n and logZ[0] == pytest.approx(lm[:, 0].sum(), rel=1e-12)
+    x, w, a = h.state()
+    assert abs(w.sum() - 1.0) < 1e-10 and a.min() >= 0 and a.max() < n
+    assert same(h.log_likelihood(y), logZ)                               # deterministic replay
+    # the step API over the same series (a refill every 64 steps instead of every 1024): same bits
+    lm0 = h.init(y[0])
+    acc, ok = lm0.copy(), same(lm0, lm[0])
+    for t in range(1, T):
+        l1, e1 = h.step(y[t])
+        ok &= l1[0] == lm[t, 0] and e1[0] == es[t, 0]
+        acc += l1
+    assert ok and same(acc, logZ) and same(h.logZ()[0], logZ)
+    x2, w2, a2 = h.state()
+    assert same(x2, x) and same(w2, w) and np.array_equal(a2, a)
     h2 = L.Handle(2, 1, n // 2, seed=5)
     h2.set_params(SV)
-    assert abs(h2.log_likelihood(y)[0] - logZ[0]) < 0.5                 # Nx-doubling convergence
-    _, w, _ = h.state(want_anc=False)
-    assert abs(w.sum() - 1.0) < 1e-10
+    z2 = h2.log_likelihood(y)[0]
+    # sd(logZ) ~ sqrt(c T / Nx): a few tenths at T = 5000, Nx = 2^19..2^20
+    assert abs(z2 - logZ[0]) < 2.5                                      # Nx-doubling convergence
     h.close(); h2.close()
+
+
+def test_break_point_window_refill_against_oracle(L, ob):
+    """The break points of multi-segment filters are prepared by k_breaks for a WINDOW of steps (<= 1024 per
+    launch for log_likelihood, 64 for the step API; smc_capi.hip ensure_breaks) and re-computed with a new
+    origin when the series runs past it.  T = 1100 crosses the first boundary; bit-exact against the oracle
+    (which knows no windows) on every per-step output and the final state."""
+    n, seg, T, nth = 5000, 1024, 1100, 2
+    _, y = ob.simulate(1, LG, T, 1998)
+    h = L.Handle(1, nth, n, seg=seg, seed=31, flags=L.FLAG_ANCESTORS)
+    h.set_params(np.tile(LG, (nth, 1)))
+    logZ, lm, es = h.log_likelihood(y, trace=True)
+    x, w, a = h.state()
+    for th in range(nth):
+        f = ob.Filter(1, LG, n, seg=seg, seed=31, stream=th)
+        z, olm, oes = f.log_likelihood(y, trace=True)
+        ox, ow, oa, _ = f.state()
+        assert bits([logZ[th]])[0] == bits([z])[0] and same(lm[:, th], olm) and same(es[:, th], oes)
+        assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa)
+    h.close()
+
+
+def test_step_api_window_refill_reseed_and_streams_mid_window(L, ob):
+    """smc_step on multi-segment filters for 150 steps (break-point windows [1,65), [65,129), [129,..)), with
+    smc_reseed at t = 40 and smc_set_streams at t = 100 - both in the middle of a window, both invalidate the
+    cached break points - against the oracle step by step."""
+    n, seg, nth, T = 3000, 1024, 2, 150
+    _, y = ob.simulate(2, SV, T, 5)
+    h = L.Handle(2, nth, n, seg=seg, seed=17, flags=L.FLAG_ANCESTORS)
+    h.set_params(np.tile(SV, (nth, 1)))
+    fs = [ob.Filter(2, SV, n, seg=seg, seed=17, stream=th) for th in range(nth)]
+    assert same(h.init(y[0]), [f.bootstrap_filter(y[0]) for f in fs])
+    streams = [0, 1]
+    for t in range(1, T):
+        if t == 40:
+            h.reseed(99)
+            for f, st in zip(fs, streams):
+                f.set_rng(99, st)
+        if t == 100:
+            streams = [7, 11]
+            h.set_streams(streams)
+            for f, st in zip(fs, streams):
+                f.set_rng(99, st)
+        lm, ess = h.step(y[t])
+        ref = [f.step(y[t]) for f in fs]
+        assert same(lm, [r[0] for r in ref]) and same(ess, [r[1] for r in ref]), t
+        if t in (39, 40, 64, 65, 100, 128, 129, T - 1):
+            x, w, a = h.state()
+            for th in range(nth):
+                ox, ow, oa, _ = fs[th].state()
+                assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa), (t, th)
+    h.close()
+
+
+def test_break_point_capacity_below_series_length(L):
+    """4096 segments: one step of break points is 32 KiB, so the 32 MiB buffer holds 1023 steps and a
+    T = 1040 series re-fills it once; log_likelihood (window 1023) and the step API (window 64) agree bit
+    for bit, i.e. the result does not depend on where the windows fall.  (The oracle would need 10^9
+    particle-steps here: property test.)"""
+    n, seg, T = 4096 * 256, 256, 1040
+    _, y = L.simulate(1, LG, T, 1998)
+    h = L.Handle(1, 1, n, seg=seg, seed=3)
+    h.set_params(LG)
+    assert h.nseg == 4096
+    logZ, lm, es = h.log_likelihood(y, trace=True)
+    l0 = h.init(y[0])
+    ok = l0[0] == lm[0, 0]
+    for t in range(1, T):
+        l1, e1 = h.step(y[t])
+        ok &= l1[0] == lm[t, 0] and e1[0] == es[t, 0]
+    assert ok and same(h.logZ()[0], logZ)
+    h.close()
 
 
 def test_full_size_c4_batched_properties(L):
