@@ -83,6 +83,45 @@ int smc_permute(smc_handle h, const int32_t* a /*[n_theta]*/);
  * filters, same geometry).  Value copy on the device; streams and parameters are not copied. */
 int smc_copy_from(smc_handle dst, smc_handle src, const uint8_t* mask /*[n_theta]*/);
 
+/* Proposals outside the prior's support: the reference never filters them (src/smc_samplers.jl:116).  Filters m with
+ * skip[m] != 0 are left out by the following smc_log_likelihood calls (their logZ reads -inf, their state is not
+ * touched); NULL runs every filter again. */
+int smc_set_skip(smc_handle h, const uint8_t* skip /*[n_theta] or NULL*/);
+
+/* ---- rejuvenate!(smc, y, xi) on the device: src/smc_samplers.jl:103-146 -------------------------
+ * The handle `prop` holds the proposal filters of this rank's parameter particles (same geometry as the online
+ * filters `main`, if any).  smc_pmmh_configure describes what a GPU cannot call as closures:
+ *   prior  = product_distribution of d_theta enumerated components (smc.prior; README.md:81-85,
+ *            examples/inflation_example.jl:33-37,234-239), par rows of SMC_PRIOR_NPAR doubles;
+ *   model  = smc.model(theta): raw parameter row k is theta[raw_from[k]] (raw_from[k] >= 0) or raw_const[k].
+ * smc_pmmh_rejuvenate then runs the whole `for c in 1:chain` loop (:113-137) for every parameter particle without
+ * a host round trip: theta' ~ MvNormal(theta, scales[c] * L L') (:114; L = lower Cholesky factor of the random-walk
+ * covariance :95-100, row-major [d][d]), insupport (:116), log_likelihood(N, y, model(theta')) with Philox seed
+ * filter_seeds[c] for the in-support proposals only (:117-121), the accept test log(rand()) < xi (logZ' - logZ) +
+ * logprior(theta') - logprior(theta) (:123-129), and theta / logZ / x / w of the accepted particles (:130-133;
+ * x, w are copied into `main` when it is not NULL).  Proposal normals and accept uniforms are Philox draws keyed by
+ * (move_seed, stream id of the filter = global theta index, chain position): independent of the sharding.
+ * theta [n_theta][d_theta] and logZ [n_theta] are read and updated in place; accepted[m] = 1 if particle m moved at
+ * least once (acc_array :135); *filters_run = number of proposal filters actually executed. */
+#define SMC_PRIOR_UNIFORM 1     /* par = (lo, hi)                                                     */
+#define SMC_PRIOR_NORMAL 2      /* par = (mu, sigma)                                                  */
+#define SMC_PRIOR_TRUNCNORMAL 3 /* par = (mu, sigma, lo, hi, log(Phi((hi-mu)/sigma) - Phi((lo-mu)/sigma))) */
+#define SMC_PRIOR_LOGNORMAL 4   /* par = (mu, sigma) of log x                                          */
+#define SMC_PRIOR_NPAR 5
+#define SMC_MAX_DTHETA 8
+int smc_pmmh_configure(smc_handle prop, int d_theta, const int32_t* prior_family /*[d_theta]*/,
+                       const double* prior_par /*[d_theta][SMC_PRIOR_NPAR]*/, const int32_t* raw_from /*[n_raw]*/,
+                       const double* raw_const /*[n_raw]*/);
+int smc_pmmh_rejuvenate(smc_handle prop, smc_handle main /*or NULL*/, const double* y, int64_t T, double xi,
+                        const double* chol /*[d_theta][d_theta]*/, const double* scales /*[chain]*/, int chain,
+                        const uint64_t* filter_seeds /*[chain]*/, uint64_t move_seed, double* theta /*[n_theta][d_theta]*/,
+                        double* logZ /*[n_theta]*/, uint8_t* accepted /*[n_theta] or NULL*/, int64_t* filters_run /*or NULL*/);
+/* the spec's PMMH pieces on the host (parity tests): proposal, log prior (NaN-free; -inf outside the support) */
+int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
+                          const double* chol, double scale, double* prop);
+double smc_host_pmmh_log_uniform(uint64_t move_seed, uint32_t stream, uint32_t c);
+double smc_host_prior_logpdf(int family, const double* par /*[SMC_PRIOR_NPAR]*/, double x);
+
 /* Moving whole filters between handles / GPUs (outer resample! of the online sampler when theta is
  * sharded, src/smc_samplers.jl:74-84 + SURVEY 8e/8f.2): pack k slots (x cloud, weights, segment records,
  * logZ) into / out of a caller-provided DEVICE buffer of k * smc_slot_bytes() bytes (e.g. a torch tensor

@@ -82,6 +82,13 @@ def lib():
         L.orc_filter_quantiles.restype = C.c_int
         L.orc_log_likelihood_batch.argtypes = [C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_uint64,
                                                C.c_uint32, _dp, C.c_int, _dp]
+        L.orc_prior_insupport.argtypes = [C.c_int, _dp, C.c_double]
+        L.orc_prior_logpdf.restype = C.c_double
+        L.orc_prior_logpdf.argtypes = [C.c_int, _dp, C.c_double]
+        L.orc_pmmh_propose.restype = None
+        L.orc_pmmh_propose.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, _dp, _dp, C.c_double, _dp]
+        L.orc_pmmh_log_uniform.restype = C.c_double
+        L.orc_pmmh_log_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
 
@@ -259,6 +266,29 @@ def log_likelihood_batch(model, raw, n, y, seg=0, seed=1, stream0=0):
     rc = lib().orc_log_likelihood_batch(model, _d(raw), nth, n, seg, seed, stream0, _d(y), y.size, _d(out))
     assert rc == 0
     return out
+
+
+def prior_insupport(fam, par, x):
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    return bool(lib().orc_prior_insupport(int(fam), _d(par), float(x)))
+
+
+def prior_logpdf(fam, par, x):
+    par = np.ascontiguousarray(par, dtype=np.float64)
+    return lib().orc_prior_logpdf(int(fam), _d(par), float(x))
+
+
+def pmmh_propose(seed, stream, c, theta, chol, scale):
+    """theta' ~ MvNormal(theta, scale * L L') with the spec's Philox normals (smc_samplers.jl:114)"""
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    chol = np.ascontiguousarray(chol, dtype=np.float64)
+    out = np.zeros(theta.size)
+    lib().orc_pmmh_propose(theta.size, int(seed), int(stream), int(c), _d(theta), _d(chol), float(scale), _d(out))
+    return out
+
+
+def pmmh_log_uniform(seed, stream, c):
+    return lib().orc_pmmh_log_uniform(int(seed), int(stream), int(c))
 
 
 def kalman_log_likelihood(raw, y, predict_first=False):

@@ -860,6 +860,57 @@ void orc_kalman_log_likelihood(const double* raw, const double* y, int64_t T, in
     out[0] = x; out[1] = S; out[2] = logZ;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* PMMH rejuvenation pieces   rejuvenate!  src/smc_samplers.jl:103-146                    */
+/* (the loop over parameter particles and chain positions is tests/oracle_backend.py)     */
+/* ------------------------------------------------------------------------------------ */
+#define SLOT_PMMH_Z 32u   /* proposal normals of a parameter particle: Philox pair k holds z[2k], z[2k+1] */
+#define SLOT_PMMH_U 33u   /* the uniform of its accept test */
+#define ORC_PRIOR_UNIFORM 1      /* par = (lo, hi) */
+#define ORC_PRIOR_NORMAL 2       /* par = (mu, sigma) */
+#define ORC_PRIOR_TRUNCNORMAL 3  /* par = (mu, sigma, lo, hi, log(Phi(b) - Phi(a))) */
+#define ORC_PRIOR_LOGNORMAL 4    /* par = (mu, sigma) of log x */
+
+/* insupport(prior_i, x)  smc_samplers.jl:116 (closed intervals as in Distributions.jl) */
+int orc_prior_insupport(int fam, const double* par, double x) {
+    switch (fam) {
+    case ORC_PRIOR_UNIFORM: return par[0] <= x && x <= par[1];
+    case ORC_PRIOR_NORMAL: return isfinite(x);
+    case ORC_PRIOR_TRUNCNORMAL: return par[2] <= x && x <= par[3];
+    case ORC_PRIOR_LOGNORMAL: return x > 0.0 && isfinite(x);
+    }
+    return 0;
+}
+/* logpdf(prior_i, x)  smc_samplers.jl:123;  -inf outside the support */
+double orc_prior_logpdf(int fam, const double* par, double x) {
+    if (!orc_prior_insupport(fam, par, x)) return -INFINITY;
+    if (fam == ORC_PRIOR_UNIFORM) return -orc_log(par[1] - par[0]);
+    if (fam == ORC_PRIOR_LOGNORMAL) {
+        const double lx = orc_log(x), z = (lx - par[0]) / par[1];
+        return (-0.5 * (z * z + LOG2PI) - orc_log(par[1])) - lx;
+    }
+    const double z = (x - par[0]) / par[1];
+    const double l = -0.5 * (z * z + LOG2PI) - orc_log(par[1]);
+    return fam == ORC_PRIOR_TRUNCNORMAL ? l - par[4] : l;
+}
+/* theta' = rand(MvNormal(theta, scale * L L'))  smc_samplers.jl:99-100,114: theta'_i = theta_i + sqrt(scale) sum_{k<=i} L_ik z_k */
+void orc_pmmh_propose(int d, uint64_t seed, uint32_t stream, uint32_t c, const double* theta, const double* L, double scale, double* prop) {
+    double z[10];
+    for (int k = 0; k < d; k += 2) normal_pair(seed, k >> 1, stream, c, SLOT_PMMH_Z, z + k);
+    const double sq = sqrt(scale);
+    for (int i = 0; i < d; ++i) {
+        double a = 0.0;
+        for (int k = 0; k <= i; ++k) a = a + L[i * d + k] * z[k];
+        prop[i] = theta[i] + sq * a;
+    }
+}
+/* log(rand()) of the accept test  smc_samplers.jl:129 */
+double orc_pmmh_log_uniform(uint64_t seed, uint32_t stream, uint32_t c) {
+    uint32_t wd[4];
+    draw(seed, 0, stream, c, SLOT_PMMH_U, wd);
+    return orc_log((double)((((((uint64_t)wd[1] << 32) | wd[0]) >> 11)) + 1) * TWO_M53);
+}
+
 /* Weighted quantiles of state coordinate `comp` under the current weights: what
  * quantile(smc.x[i], weights(smc.w[i]), p) delivers per theta-particle in examples/inflation_example.jl:45
  * (StatsBase.jl, not vendored).  Definition used here (integer, order-free): with W_i = q_i >> sh_b the

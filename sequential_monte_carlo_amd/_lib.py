@@ -21,7 +21,10 @@ EXPORTS = [
     "smc_last_elapsed_ms", "smc_synchronize", "smc_time_step_kernel", "smc_event_overhead_ms", "smc_normalize", "smc_resample", "smc_kalman_log_likelihood", "smc_get_moments", "smc_get_quantiles", "smc_simulate", "smc_model_dim",
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
     "smc_host_box_muller", "smc_sys_targets", "smc_device_math", "smc_last_error", "smc_version",
+    "smc_set_skip", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_host_pmmh_propose", "smc_host_pmmh_log_uniform",
+    "smc_host_prior_logpdf",
 ]
+PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
 
 _dp = C.POINTER(C.c_double)
 _u64p = C.POINTER(C.c_uint64)
@@ -108,6 +111,15 @@ def lib():
     L.smc_host_box_muller.restype = None
     L.smc_host_box_muller.argtypes = [_u32p, _dp, _dp]
     L.smc_device_math.argtypes = [C.c_int, _dp, _dp, C.c_int64, _dp, C.c_int]
+    L.smc_set_skip.argtypes = [h, C.POINTER(C.c_uint8)]
+    L.smc_pmmh_configure.argtypes = [h, C.c_int, _i32p, _dp, _i32p, _dp]
+    L.smc_pmmh_rejuvenate.argtypes = [h, h, _dp, C.c_int64, C.c_double, _dp, _dp, C.c_int, _u64p, C.c_uint64, _dp, _dp,
+                                      C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
+    L.smc_host_pmmh_propose.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, _dp, _dp, C.c_double, _dp]
+    L.smc_host_pmmh_log_uniform.restype = C.c_double
+    L.smc_host_pmmh_log_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    L.smc_host_prior_logpdf.restype = C.c_double
+    L.smc_host_prior_logpdf.argtypes = [C.c_int, _dp, C.c_double]
     L.smc_last_error.restype = C.c_char_p
     L.smc_version.restype = C.c_char_p
     _lib = L
@@ -273,6 +285,43 @@ class Handle:
         m = np.ascontiguousarray(mask, dtype=np.uint8)
         assert m.size == self.n_theta
         check(lib().smc_copy_from(self._h, src._h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def set_skip(self, skip):
+        """filters the following log_likelihood calls leave out (logZ = -inf); None: run all again"""
+        if skip is None:
+            check(lib().smc_set_skip(self._h, None))
+            return
+        m = np.ascontiguousarray(skip, dtype=np.uint8)
+        assert m.size == self.n_theta
+        check(lib().smc_set_skip(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def pmmh_configure(self, families, pars, raw_from, raw_const):
+        """prior components and the theta -> parameter-row map of smc_pmmh_rejuvenate (see include/smc_hip.h)"""
+        fam = np.ascontiguousarray(families, dtype=np.int32)
+        par = np.ascontiguousarray(pars, dtype=np.float64).reshape(fam.size, PRIOR_NPAR)
+        rf = np.ascontiguousarray(raw_from, dtype=np.int32)
+        rc = np.ascontiguousarray(raw_const, dtype=np.float64)
+        assert rf.size == rc.size == lib().smc_model_nraw(self.model_id)
+        check(lib().smc_pmmh_configure(self._h, fam.size, fam.ctypes.data_as(_i32p), _d(par), rf.ctypes.data_as(_i32p), _d(rc)))
+        self._pmmh_d = int(fam.size)
+
+    def pmmh_rejuvenate(self, main, y, xi, chol, scales, filter_seeds, move_seed, theta, logZ):
+        """rejuvenate!(smc, y, xi) for this handle's parameter particles, on the device.
+        Returns (theta, logZ, accepted, filters_run); theta / logZ are new arrays."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        d = self._pmmh_d
+        theta = np.array(theta, dtype=np.float64, order="C").reshape(self.n_theta, d)
+        logZ = np.array(logZ, dtype=np.float64, order="C").reshape(self.n_theta)
+        chol = np.ascontiguousarray(chol, dtype=np.float64).reshape(d, d)
+        scales = np.ascontiguousarray(scales, dtype=np.float64)
+        seeds = np.ascontiguousarray(filter_seeds, dtype=np.uint64)
+        assert seeds.size == scales.size
+        acc = np.zeros(self.n_theta, dtype=np.uint8)
+        nrun = C.c_int64()
+        check(lib().smc_pmmh_rejuvenate(self._h, main._h if main is not None else None, _d(y), y.size, float(xi), _d(chol),
+                                        _d(scales), scales.size, seeds.ctypes.data_as(_u64p), int(move_seed), _d(theta), _d(logZ),
+                                        acc.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(nrun)))
+        return theta, logZ, acc.astype(bool), int(nrun.value)
 
     def slot_bytes(self):
         b = C.c_int64()

@@ -300,6 +300,61 @@ __global__ void k_copy_slots(FilterView dst, int dcur, FilterView src, int scur,
 }
 
 // ---------------------------------------------------------------------------------------------
+// PMMH rejuvenation on the device (rejuvenate!, smc_samplers.jl:103-146): one lane per parameter particle.
+//   k_pmmh_propose  theta' ~ MvNormal(theta, scale Sigma) (:114), insupport (:116), prior logpdfs (:123), and the
+//                   parameter row smc.model(theta') of the proposal filter (:120)
+//   [the proposal filters run: log_likelihood over y for every in-support theta']
+//   k_pmmh_accept   the accept test (:123-129) and theta / logZ of the accepted particles (:130-131); the filter
+//                   state x, w (:132-133) is then copied by k_copy_slots under the same mask
+// ---------------------------------------------------------------------------------------------
+struct PmmhDev {
+    double* theta;        // [ntheta][MAX_DTHETA] current parameter particles
+    double* prop;         // [ntheta][MAX_DTHETA] proposals of this chain position
+    double* logZ;         // [ntheta] log-likelihood estimates of the current particles
+    double* lp;           // [ntheta][2] log prior of (proposal, current)
+    unsigned char* skip;  // [ntheta] proposal outside the support: its filter is not run
+    unsigned char* mask;  // [ntheta] accepted at this chain position
+    unsigned char* any;   // [ntheta] accepted at least once in this rejuvenation (acc_array, :135)
+    unsigned long long* nrun;   // [1] proposal filters executed so far
+    double* chol;         // [d][d] lower Cholesky factor of the random-walk covariance (:95-100)
+};
+__global__ void k_pmmh_propose(FilterView v, PmmhSpec s, PmmhDev p, int model, uint64_t move_seed, uint32_t c, double sq, Params* params) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= v.ntheta) return;
+    const double* th = p.theta + (size_t)m * MAX_DTHETA;
+    double pr[MAX_DTHETA];
+    pmmh_propose(s, move_seed, v.stream[m], c, th, p.chol, sq, pr);
+    const bool ok = pmmh_insupport(s, pr);
+    p.skip[m] = ok ? 0 : 1;
+    for (int i = 0; i < s.d; ++i) p.prop[(size_t)m * MAX_DTHETA + i] = pr[i];
+    if (!ok) return;
+    p.lp[2 * (size_t)m] = pmmh_logprior(s, pr);
+    p.lp[2 * (size_t)m + 1] = pmmh_logprior(s, th);
+    Params P;
+    pmmh_raw_row(s, pr, P.raw);
+    derive_params(model, P.raw, P.der);
+    params[m] = P;
+}
+__global__ void k_pmmh_accept(FilterView v, PmmhDev p, int d, uint64_t move_seed, uint32_t c, double xi) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= v.ntheta) return;
+    bool acc = false;
+    if (!p.skip[m]) {
+        const double logZp = v.logZ[m], lpp = p.lp[2 * (size_t)m], lpc = p.lp[2 * (size_t)m + 1];
+        const double likelihood_ratio = xi * (logZp - p.logZ[m]), prior_ratio = lpp - lpc;
+        const double acc_ratio = likelihood_ratio + prior_ratio, log_post_prop = logZp + lpp;
+        acc = log_post_prop > -inf() && pmmh_log_uniform(move_seed, v.stream[m], c) < acc_ratio;
+        atomicAdd(p.nrun, 1ull);
+        if (acc) {
+            for (int i = 0; i < d; ++i) p.theta[(size_t)m * MAX_DTHETA + i] = p.prop[(size_t)m * MAX_DTHETA + i];
+            p.logZ[m] = logZp;
+            p.any[m] = 1;
+        }
+    }
+    p.mask[m] = acc ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // stand-alone A1 / A2 (outer theta-level reweight / resample; n <= a few thousand): one
 // workgroup, single level, all integer sums.
 // ---------------------------------------------------------------------------------------------

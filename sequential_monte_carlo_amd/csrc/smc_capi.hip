@@ -51,6 +51,13 @@ struct smc_filter_s {
     uint64_t* d_brk = nullptr;                 // break points of the steps [v.brk_t0, v.brk_t0 + brk_count)
     uint32_t brk_cap = 0, brk_count = 0;
     int64_t reccap = 0;
+    unsigned char* d_skip = nullptr;           // smc_set_skip: filters log_likelihood leaves out
+    bool skip_on = false;
+    // PMMH rejuvenation state (smc_pmmh_configure / smc_pmmh_rejuvenate): this handle holds the proposal filters
+    PmmhSpec pm_spec{};
+    bool pm_cfg = false;
+    PmmhDev pm{};
+    double* h_pm_out = nullptr;                // pinned mirror: theta [ntheta][d] | logZ [ntheta] | any [ntheta] | nrun
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cur = 0;
@@ -314,6 +321,10 @@ extern "C" int smc_destroy(smc_handle h) {
         (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]);
     }
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
+    (void)hipFree(h->d_skip);
+    (void)hipFree(h->pm.theta); (void)hipFree(h->pm.prop); (void)hipFree(h->pm.logZ); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip);
+    (void)hipFree(h->pm.mask); (void)hipFree(h->pm.any); (void)hipFree(h->pm.nrun); (void)hipFree(h->pm.chol);
     if (h->d_brk) (void)hipFree(h->d_brk);
     if (h->d_q) (void)hipFree(h->d_q);
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
@@ -451,6 +462,36 @@ extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
     return finish_timing(h, nullptr, logmu, ess);
 }
 
+// The launches of log_likelihood(N, y, model) (particles.jl:132-147) for every filter of the handle, enqueued on
+// its stream: nothing here waits for the device.  y must already be in h->d_y (ensure_y + copy by the caller).
+static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_trace) {
+    const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
+    h->v.y = h->d_y;
+    h->v.trace_logmu = want_trace ? h->d_tr_logmu : nullptr;
+    h->v.trace_ess = want_trace ? h->d_tr_ess : nullptr;
+    h->cur = 0;
+    h->v.want_s2 = want_trace ? 1 : 0;   // ess_t is read only through the traces; the last step always has it
+    int rc = SMC_OK;
+    if (resident) {
+        HIPCHK(do_resident(h, (int)T));
+        h->cur = 0; h->t = (uint32_t)T; h->inited = true; h->emitted = true;
+    } else {
+        if (T == 1) h->v.want_s2 = 1;
+        HIPCHK(do_init(h, y0));
+        h->t = 1; h->inited = true; h->emitted = false;
+        for (int64_t t = 1; t < T; ++t) {
+            if (t == T - 1) h->v.want_s2 = 1;
+            HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
+            HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
+            h->cur ^= 1; h->t += 1;
+        }
+        rc = emit_if_needed(h);
+    }
+    h->v.want_s2 = 1;
+    h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
+    return rc;
+}
+
 // log_likelihood(N, y, model)   particles.jl:132-147
 extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, double* logZ, double* logmu_trace,
                                   double* ess_trace) {
@@ -465,34 +506,147 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
     if (resident && (rc = ensure_recs(h, T))) return rc;
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
-    h->v.y = h->d_y;
-    h->v.trace_logmu = want_trace ? h->d_tr_logmu : nullptr;
-    h->v.trace_ess = want_trace ? h->d_tr_ess : nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    h->cur = 0;
-    h->v.want_s2 = want_trace ? 1 : 0;   // ess_t is read only through the traces; the last step always has it
-    if (resident) {
-        HIPCHK(do_resident(h, (int)T));
-        h->cur = 0; h->t = (uint32_t)T; h->inited = true; h->emitted = true;
-    } else {
-        if (T == 1) h->v.want_s2 = 1;
-        HIPCHK(do_init(h, y[0]));
-        h->t = 1; h->inited = true; h->emitted = false;
-        for (int64_t t = 1; t < T; ++t) {
-            if (t == T - 1) h->v.want_s2 = 1;
-            HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
-            HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
-            h->cur ^= 1; h->t += 1;
-        }
-        rc = emit_if_needed(h);
-        if (rc) return rc;
-    }
-    h->v.want_s2 = 1;
+    h->v.skip = h->skip_on ? h->d_skip : nullptr;
+    rc = enqueue_log_likelihood(h, y[0], T, want_trace);
+    h->v.skip = nullptr;
+    if (rc) return rc;
     rc = finish_timing(h, logZ);
-    h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     if (rc) return rc;
     if (logmu_trace) HIPCHK(hipMemcpy(logmu_trace, h->d_tr_logmu, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
     if (ess_trace) HIPCHK(hipMemcpy(ess_trace, h->d_tr_ess, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
+
+// Filters smc_log_likelihood leaves out (logZ = -inf): the proposals outside the prior's support, for which the
+// reference never calls log_likelihood (smc_samplers.jl:116).  NULL: run every filter again.
+extern "C" int smc_set_skip(smc_handle h, const uint8_t* skip) {
+    if (!h) return fail(SMC_EINVAL, "smc_set_skip: NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!skip) { h->skip_on = false; return SMC_OK; }
+    if (!h->d_skip) HIPCHK(dalloc(&h->d_skip, (size_t)h->v.ntheta));
+    HIPCHK(hipMemcpyAsync(h->d_skip, skip, (size_t)h->v.ntheta, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->skip_on = true;
+    return SMC_OK;
+}
+
+// ---- PMMH rejuvenation on the device (rejuvenate!, smc_samplers.jl:103-146) --------------------------------
+extern "C" int smc_pmmh_configure(smc_handle h, int d_theta, const int32_t* prior_family, const double* prior_par,
+                                  const int32_t* raw_from, const double* raw_const) {
+    if (!h || !prior_family || !prior_par || !raw_from || !raw_const) return fail(SMC_EINVAL, "smc_pmmh_configure: NULL argument");
+    if (d_theta < 1 || d_theta > MAX_DTHETA) return fail(SMC_EINVAL, "smc_pmmh_configure: 1 <= d_theta <= 8");
+    PmmhSpec sp{};
+    sp.d = d_theta;
+    for (int i = 0; i < d_theta; ++i) {
+        if (prior_family[i] < PRIOR_UNIFORM || prior_family[i] > PRIOR_LOGNORMAL)
+            return fail(SMC_EINVAL, "smc_pmmh_configure: unknown prior family " + std::to_string(prior_family[i]));
+        sp.family[i] = prior_family[i];
+        for (int k = 0; k < PRIOR_NPAR; ++k) sp.par[i][k] = prior_par[(size_t)i * PRIOR_NPAR + k];
+    }
+    sp.nraw = model_nraw_rt(h->model);
+    for (int k = 0; k < sp.nraw; ++k) {
+        if (raw_from[k] >= d_theta) return fail(SMC_EINVAL, "smc_pmmh_configure: raw_from index out of range");
+        sp.raw_from[k] = raw_from[k];
+        sp.raw_const[k] = raw_const[k];
+    }
+    HIPCHK(hipSetDevice(h->device));
+    const size_t nt = (size_t)h->v.ntheta;
+    if (!h->pm.theta) {
+        HIPCHK(dalloc(&h->pm.theta, nt * MAX_DTHETA));
+        HIPCHK(dalloc(&h->pm.prop, nt * MAX_DTHETA));
+        HIPCHK(dalloc(&h->pm.logZ, nt));
+        HIPCHK(dalloc(&h->pm.lp, nt * 2));
+        HIPCHK(dalloc(&h->pm.skip, nt));
+        HIPCHK(dalloc(&h->pm.mask, nt));
+        HIPCHK(dalloc(&h->pm.any, nt));
+        HIPCHK(dalloc(&h->pm.nrun, 1));
+        HIPCHK(dalloc(&h->pm.chol, MAX_DTHETA * MAX_DTHETA));
+        HIPCHK(hipHostMalloc((void**)&h->h_pm_out, (nt * (MAX_DTHETA + 2) + 1) * 8, hipHostMallocDefault));
+    }
+    h->pm_spec = sp;
+    h->pm_cfg = true;
+    return SMC_OK;
+}
+
+__global__ void k_pmmh_export(int ntheta, int d, PmmhDev p, double* out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= ntheta) return;
+    for (int i = 0; i < d; ++i) out[(size_t)m * d + i] = p.theta[(size_t)m * MAX_DTHETA + i];
+    out[(size_t)ntheta * d + m] = p.logZ[m];
+    out[(size_t)ntheta * (d + 1) + m] = p.any[m] ? 1.0 : 0.0;
+    if (m == 0) out[(size_t)ntheta * (d + 2)] = (double)*p.nrun;
+}
+
+extern "C" int smc_pmmh_rejuvenate(smc_handle h, smc_handle main, const double* y, int64_t T, double xi, const double* chol,
+                                   const double* scales, int chain, const uint64_t* filter_seeds, uint64_t move_seed,
+                                   double* theta, double* logZ, uint8_t* accepted, int64_t* filters_run) {
+    if (!h || !y || !chol || !scales || !filter_seeds || !theta || !logZ) return fail(SMC_EINVAL, "smc_pmmh_rejuvenate: NULL argument");
+    if (!h->pm_cfg) return fail(SMC_ESTATE, "smc_pmmh_rejuvenate: smc_pmmh_configure has not been called");
+    if (T <= 0 || chain < 0) return fail(SMC_EINVAL, "smc_pmmh_rejuvenate: bad T or chain");
+    if (main) {
+        if (main == h) return fail(SMC_EINVAL, "smc_pmmh_rejuvenate: main and proposal handles are the same");
+        const FilterView &a = main->v, &b = h->v;
+        if (main->model != h->model || a.n != b.n || a.seg != b.seg || a.ntheta != b.ntheta || main->device != h->device)
+            return fail(SMC_EINVAL, "smc_pmmh_rejuvenate: handles differ in model, geometry or device");
+        if (!main->inited) return fail(SMC_ESTATE, "smc_pmmh_rejuvenate: main filters not initialised");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    const PmmhSpec& sp = h->pm_spec;
+    const int nt = h->v.ntheta, d = sp.d;
+    int rc = ensure_y(h, T);
+    if (rc) return rc;
+    const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
+    if (resident && (rc = ensure_recs(h, T))) return rc;
+    if (main) {   // its pending emission, then an idle stream: the accept copies below run on the proposal handle's stream
+        if ((rc = emit_if_needed(main))) return rc;
+        HIPCHK(hipStreamSynchronize(main->stream));
+    }
+    std::vector<double> th8((size_t)nt * MAX_DTHETA, 0.0), L8((size_t)MAX_DTHETA * MAX_DTHETA, 0.0);
+    for (int m = 0; m < nt; ++m)
+        for (int i = 0; i < d; ++i) th8[(size_t)m * MAX_DTHETA + i] = theta[(size_t)m * d + i];
+    for (int i = 0; i < d * d; ++i) L8[i] = chol[i];
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pm.theta, th8.data(), th8.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pm.logZ, logZ, (size_t)nt * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pm.chol, L8.data(), L8.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->pm.any, 0, (size_t)nt, h->stream));
+    HIPCHK(hipMemsetAsync(h->pm.nrun, 0, 8, h->stream));
+    const dim3 grid((unsigned)((nt + 127) / 128)), block(128);
+    for (int c = 0; c < chain; ++c) {
+        hipLaunchKernelGGL(k_pmmh_propose, grid, block, 0, h->stream, h->v, sp, h->pm, h->model, move_seed, (uint32_t)c,
+                           sqrt(scales[c]), h->d_params);
+        HIPCHK(hipGetLastError());
+        h->have_params = true;
+        h->v.seed = filter_seeds[c];
+        h->brk_count = 0;                      // cached break points belong to the previous seed
+        h->v.skip = h->pm.skip;
+        rc = enqueue_log_likelihood(h, y[0], T, false);
+        h->v.skip = nullptr;
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pmmh_accept, grid, block, 0, h->stream, h->v, h->pm, d, move_seed, (uint32_t)c, xi);
+        HIPCHK(hipGetLastError());
+        if (main) {   // smc.x[m], smc.w[m] <- x_prop, w_prop of the accepted particles (smc_samplers.jl:132-133)
+            const FilterView& a = main->v;
+            hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)((a.npad + 255) / 256), a.ntheta), dim3(256), 0, h->stream, a, main->cur,
+                               h->v, h->cur, main->d, h->pm.mask);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    hipLaunchKernelGGL(k_pmmh_export, grid, block, 0, h->stream, nt, d, h->pm, h->h_pm_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    if (main && chain > 0) main->t = h->t;
+    memcpy(theta, h->h_pm_out, (size_t)nt * d * 8);
+    memcpy(logZ, h->h_pm_out + (size_t)nt * d, (size_t)nt * 8);
+    if (accepted)
+        for (int m = 0; m < nt; ++m) accepted[m] = h->h_pm_out[(size_t)nt * (d + 1) + m] != 0.0 ? 1 : 0;
+    if (filters_run) *filters_run = (int64_t)h->h_pm_out[(size_t)nt * (d + 2)];
     return SMC_OK;
 }
 
@@ -900,6 +1054,19 @@ extern "C" void smc_host_philox4x32_10(const uint32_t ctr[4], const uint32_t key
 }
 extern "C" void smc_host_box_muller(const uint32_t w[4], double* z0, double* z1) {
     box_muller(u32x4{{w[0], w[1], w[2], w[3]}}, *z0, *z1);
+}
+
+extern "C" int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
+                                     const double* chol, double scale, double* prop) {
+    if (d_theta < 1 || d_theta > MAX_DTHETA || !theta || !chol || !prop) return fail(SMC_EINVAL, "smc_host_pmmh_propose: bad argument");
+    PmmhSpec sp{};
+    sp.d = d_theta;
+    pmmh_propose(sp, move_seed, stream, c, theta, chol, sqrt(scale), prop);
+    return SMC_OK;
+}
+extern "C" double smc_host_pmmh_log_uniform(uint64_t move_seed, uint32_t stream, uint32_t c) { return pmmh_log_uniform(move_seed, stream, c); }
+extern "C" double smc_host_prior_logpdf(int family, const double* par, double x) {
+    return prior_insupport(family, par, x) ? prior_logpdf(family, par, x) : -inf();
 }
 
 __global__ void k_device_math(int which, const double* a, const double* b, int64_t n, double* out) {

@@ -71,6 +71,8 @@ struct FilterView {
                              //    (one workgroup owns the whole filter), so no finalize launch follows
     int want_s2;             // 1: accumulate sum q^2 (ESS) in this launch; 0: its consumer never reads it
                              //    (log_likelihood discards ess, particles.jl:142: only the last step / traces need it)
+    const unsigned char* skip;   // [ntheta] or nullptr: filters with skip[th] != 0 are not run by log_likelihood (PMMH proposals
+                             //    outside the prior's support, smc_samplers.jl:116); their logZ reads -inf
     int abl;                 // ablation mask: always 0 in the product (profiling builds only, -DSMC_ABLATE)
     unsigned long long* dbg; // phase stamps [workgroup][8] (profiling builds only), else nullptr
 };
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* scr = (uint64_t*)smem;
     const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = threadIdx.x;
+    if (v.skip && v.skip[th]) return;   // workgroup-uniform
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
     const int64_t seg0 = (int64_t)sb * v.seg;
@@ -594,6 +597,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     constexpr int SEGP = lds_padded_len(SEG);   // padded length of a staged segment in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = threadIdx.x;
+    if (v.skip && v.skip[th]) return;   // workgroup-uniform
     const int nxt = cur ^ 1;
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
@@ -945,6 +949,13 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_finalize(FilterView v, int cur, int first_emit, uint32_t t_emit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (v.skip && v.skip[blockIdx.x]) {   // a filter that was not run: logZ = -inf
+        if (threadIdx.x == 0) {
+            v.logZ[blockIdx.x] = -inf();
+            if (v.host_out) v.host_out[blockIdx.x] = -inf();
+        }
+        return;
+    }
     const TableLds L = carve(smem, v.nseg_p2);
     table_prologue<THREADS>(v, cur, blockIdx.x, L, true, first_emit != 0, t_emit);
 }

@@ -27,6 +27,13 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     uint64_t* usys = scr + scr_words(THREADS, NP) - 8;   // SYS: the steps' uniforms (tail words nobody else uses)
     constexpr int NU = (THREADS / WAVE) < 8 ? (THREADS / WAVE) : 8;
     const int th = blockIdx.x, tid = threadIdx.x;
+    if (v.skip && v.skip[th]) {   // a filter that is not run (proposal outside the prior's support): logZ = -inf
+        if (tid == 0) {
+            v.logZ[th] = -inf();
+            if (v.host_out) v.host_out[th] = -inf();
+        }
+        return;
+    }
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
     StepRec* rec = recs + (size_t)th * T;

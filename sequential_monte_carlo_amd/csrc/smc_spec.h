@@ -30,6 +30,9 @@ constexpr uint32_t SLOT_OBS = 8u;        // simulate(): observation noise
 constexpr uint32_t SLOT_COUNT = 9u;      // segment pick of draw i (multi-segment filters)
 constexpr uint32_t SLOT_SYS = 10u;       // the one uniform of a systematic resampling step (opt-in)
 constexpr uint32_t SLOT_BREAK = 16u;     // block break points: 16+2i normal, 17+2i uniform, i < 8; pair = block
+constexpr uint32_t SLOT_PMMH_Z = 32u;    // PMMH proposal normals of a parameter particle: pair k holds z[2k], z[2k+1]
+constexpr uint32_t SLOT_PMMH_U = 33u;    // the uniform of its accept test
+constexpr int MAX_DTHETA = 8;            // parameter dimension of the samplers (SMC_MAX_DTHETA)
 
 constexpr double HALF_LOG2PI = 0x1.d67f1c864beb5p-1;
 constexpr double INV_LN2 = 0x1.71547652b82fep+0;
@@ -418,6 +421,84 @@ SMC_HD void model_obs_moments(const Params& p, const double* x, double& mean, do
         mean = x[0];
         sd = sp_exp(0.5 * x[2]);
     }
+}
+
+// ---- PMMH rejuvenation of the samplers (src/smc_samplers.jl:103-146), one parameter particle ------------------
+// Random numbers are counter based like everything else: key = the move's seed, stream = GLOBAL index of the
+// parameter particle (so results do not depend on how theta is sharded), t = chain position.
+constexpr int PRIOR_UNIFORM = 1;      // par = (lo, hi)
+constexpr int PRIOR_NORMAL = 2;       // par = (mu, sigma)
+constexpr int PRIOR_TRUNCNORMAL = 3;  // par = (mu, sigma, lo, hi, log(Phi((hi-mu)/sigma) - Phi((lo-mu)/sigma)))
+constexpr int PRIOR_LOGNORMAL = 4;    // par = (mu, sigma) of log x
+constexpr int PRIOR_NPAR = 5;
+struct PmmhSpec {
+    int d;                              // parameter dimension
+    int family[MAX_DTHETA];             // product_distribution([...]) component by component
+    double par[MAX_DTHETA][PRIOR_NPAR];
+    int nraw;                           // smc.model(theta): raw[k] = raw_from[k] >= 0 ? theta[raw_from[k]] : raw_const[k]
+    int raw_from[NPARAM];
+    double raw_const[NPARAM];
+};
+SMC_HD bool finite_d(double x) { return x == x && x != inf() && x != -inf(); }
+// insupport(prior_i, x)   (smc_samplers.jl:116; Distributions' closed intervals)
+SMC_HD bool prior_insupport(int fam, const double* par, double x) {
+    switch (fam) {
+    case PRIOR_UNIFORM: return par[0] <= x && x <= par[1];
+    case PRIOR_NORMAL: return finite_d(x);
+    case PRIOR_TRUNCNORMAL: return par[2] <= x && x <= par[3];
+    case PRIOR_LOGNORMAL: return x > 0.0 && finite_d(x);
+    }
+    return false;
+}
+// logpdf(prior_i, x) for x in the support   (smc_samplers.jl:123; Normal: -(z^2 + log 2pi)/2 - log sigma)
+SMC_HD double prior_logpdf(int fam, const double* par, double x) {
+    switch (fam) {
+    case PRIOR_UNIFORM: return -sp_log(par[1] - par[0]);
+    case PRIOR_NORMAL: {
+        const double z = (x - par[0]) / par[1];
+        return -0.5 * (z * z + 2.0 * HALF_LOG2PI) - sp_log(par[1]);
+    }
+    case PRIOR_TRUNCNORMAL: {
+        const double z = (x - par[0]) / par[1];
+        return (-0.5 * (z * z + 2.0 * HALF_LOG2PI) - sp_log(par[1])) - par[4];
+    }
+    case PRIOR_LOGNORMAL: {
+        const double lx = sp_log(x), z = (lx - par[0]) / par[1];
+        return (-0.5 * (z * z + 2.0 * HALF_LOG2PI) - sp_log(par[1])) - lx;
+    }
+    }
+    return -inf();
+}
+// insupport / logpdf of the product prior: components in order, sum from 0.0 left to right
+SMC_HD bool pmmh_insupport(const PmmhSpec& s, const double* th) {
+    bool ok = true;
+    for (int i = 0; i < s.d; ++i) ok = ok && prior_insupport(s.family[i], s.par[i], th[i]);
+    return ok;
+}
+SMC_HD double pmmh_logprior(const PmmhSpec& s, const double* th) {
+    double lp = 0.0;
+    for (int i = 0; i < s.d; ++i) lp = lp + prior_logpdf(s.family[i], s.par[i], th[i]);
+    return lp;
+}
+// theta' = rand(MvNormal(theta, scale * Sigma)), Sigma = L L'  (smc_samplers.jl:99-100,114):
+// theta'_i = theta_i + sq * sum_{k<=i} L[i][k] z_k, sq = sqrt(scale), the sum taken left to right
+SMC_HD void pmmh_propose(const PmmhSpec& s, uint64_t seed, uint32_t stream, uint32_t c, const double* th, const double* L /*[d][d]*/,
+                         double sq, double* prop) {
+    double z[MAX_DTHETA + 1];
+    for (int k = 0; k < s.d; k += 2) box_muller(draw(seed, (uint32_t)(k >> 1), stream, c, SLOT_PMMH_Z), z[k], z[k + 1]);
+    for (int i = 0; i < s.d; ++i) {
+        double a = 0.0;
+        for (int k = 0; k <= i; ++k) a = a + L[i * s.d + k] * z[k];
+        prop[i] = th[i] + sq * a;
+    }
+}
+// log(rand()) of the accept test (smc_samplers.jl:129): u in (0, 1]
+SMC_HD double pmmh_log_uniform(uint64_t seed, uint32_t stream, uint32_t c) {
+    return sp_log(uniform53(draw(seed, 0u, stream, c, SLOT_PMMH_U)));
+}
+// smc.model(theta): parameter row of the model family
+SMC_HD void pmmh_raw_row(const PmmhSpec& s, const double* th, double* raw /*[NPARAM]*/) {
+    for (int k = 0; k < NPARAM; ++k) raw[k] = k < s.nraw ? (s.raw_from[k] >= 0 ? th[s.raw_from[k]] : s.raw_const[k]) : 0.0;
 }
 
 // ---- segment combine (integers only) ----------------------------------------------------------

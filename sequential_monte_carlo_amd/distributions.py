@@ -6,6 +6,9 @@ import math
 import numpy as np
 from scipy.special import ndtr, ndtri
 
+# enumerated families of the device-side PMMH (include/smc_hip.h SMC_PRIOR_*): spec() -> (family, 5 parameters)
+PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL = 1, 2, 3, 4
+
 
 class Normal:
     def __init__(self, mu=0.0, sigma=1.0):
@@ -30,6 +33,9 @@ class Normal:
 
     def insupport_v(self, x):
         return np.isfinite(x)
+
+    def spec(self):
+        return PRIOR_NORMAL, [self.mu, self.sigma, 0.0, 0.0, 0.0]
 
 
 class TruncatedNormal:
@@ -65,6 +71,9 @@ class TruncatedNormal:
         out = -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma) - self._logz
         return np.where(self.insupport_v(x), out, -np.inf)
 
+    def spec(self):
+        return PRIOR_TRUNCNORMAL, [self.mu, self.sigma, self.lo, self.hi, self._logz]
+
 
 class LogNormal:
     def __init__(self, mu=0.0, sigma=1.0):
@@ -94,6 +103,9 @@ class LogNormal:
         z = (np.log(xs) - self.mu) / self.sigma
         return np.where(ok, -0.5 * (z * z + math.log(2 * math.pi)) - math.log(self.sigma) - np.log(xs), -np.inf)
 
+    def spec(self):
+        return PRIOR_LOGNORMAL, [self.mu, self.sigma, 0.0, 0.0, 0.0]
+
 
 class Uniform:
     def __init__(self, lo=0.0, hi=1.0):
@@ -116,6 +128,9 @@ class Uniform:
 
     def logpdf_v(self, x):
         return np.where(self.insupport_v(x), -math.log(self.hi - self.lo), -np.inf)
+
+    def spec(self):
+        return PRIOR_UNIFORM, [self.lo, self.hi, 0.0, 0.0, 0.0]
 
 
 def _vec(f):
@@ -145,6 +160,14 @@ class Product:
 
     def __len__(self):
         return len(self.parts)
+
+    def spec(self):
+        """(families [d], parameters [d][5]) when every component is one of the enumerated families the device-side
+        PMMH knows (include/smc_hip.h SMC_PRIOR_*), else None (then the samplers keep rejuvenate! on the host)."""
+        if not all(hasattr(p, "spec") for p in self.parts) or len(self.parts) > 8:
+            return None
+        sp = [p.spec() for p in self.parts]
+        return np.array([f for f, _ in sp], dtype=np.int32), np.array([q for _, q in sp], dtype=np.float64)
 
     def rand(self, rng):
         return np.array([p.rand(rng) for p in self.parts])

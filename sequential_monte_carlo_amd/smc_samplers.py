@@ -5,6 +5,14 @@ the random-walk kernel) stays on the host exactly as in the reference; every par
 reference runs inside `Threads.@threads for m in 1:M` (smc_samplers.jl:112-121,174-180,223-229) or
 serially (:289-295,:325-335) becomes ONE batched call on the GPU (theta axis = workgroups).
 
+PMMH rejuvenation (rejuvenate!, smc_samplers.jl:103-146) runs entirely on the device when the sampler is given
+what a GPU can evaluate instead of closures: `theta_map=ThetaMap(...)` for smc.model(theta) and a prior made of the
+enumerated families (distributions.py spec()).  Then one smc_pmmh_rejuvenate call does the whole chain loop for
+the rank's parameter particles - proposals, insupport, prior ratio, the proposal filters, the accept test, and the
+overwrite of theta / logZ / x / w - with Philox draws keyed by the GLOBAL theta index, and no collective inside.
+With arbitrary Python closures / priors the same loop stays on the host (numpy random numbers) and only the filters
+are batched on the GPU.  Either way a proposal outside the prior's support is never filtered (:116).
+
 theta sharding (multi-GPU): pass `comm=ThetaComm(...)` (distributed.py).  Every rank holds the full
 (small) theta / logZ vectors and draws the same host random numbers from the same seed, so all ranks
 take identical decisions; a rank only *filters* its own contiguous slice of theta, and the slices of
@@ -31,6 +39,28 @@ def _rows(models):
     return (models.model_id, models.rows) if isinstance(models, RawModels) else params_matrix(models)
 
 
+class ThetaMap:
+    """smc.model(theta) in a form the device can evaluate: parameter row k of the model family `model_id` is
+    theta[raw_from[k]] when raw_from[k] >= 0, else the constant raw_const[k].
+    README.md:75-79 (LinearGaussian(theta1, 1.0, theta2, theta3, 0.0)):  ThetaMap(LG, [0,-1,1,2,-1,-1], [0,1,0,0,0,1]);
+    examples/inflation_example.jl:227-230 (UCSV(theta1, theta2, (theta3, theta4))):  ThetaMap(UCSV, [0,0,1,2,3], [0]*5)."""
+
+    def __init__(self, model_id, raw_from, raw_const):
+        self.model_id = int(model_id)
+        self.raw_from = np.ascontiguousarray(raw_from, dtype=np.int32)
+        self.raw_const = np.ascontiguousarray(raw_const, dtype=np.float64)
+        if self.raw_from.size != self.raw_const.size:
+            raise ValueError("raw_from and raw_const must have one entry per parameter of the model row")
+
+    def rows(self, thetas):
+        """[m, n_raw] parameter rows of the m parameter vectors in `thetas`"""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=np.float64))
+        out = np.tile(self.raw_const, (thetas.shape[0], 1))
+        use = self.raw_from >= 0
+        out[:, use] = thetas[:, self.raw_from[use]]
+        return out
+
+
 # ---- filter backends ---------------------------------------------------------------------------
 class HipBackend:
     """Runs the batched inner filters on one GPU through the C ABI (no CPU fallback)."""
@@ -49,19 +79,41 @@ class HipBackend:
         h.reseed(seed)
         return h
 
-    def log_likelihood(self, models, N, y, seed, streams, key="prop"):
-        mid, raw = _rows(models)
-        h = self._handle(key, mid, raw.shape[0], N, seed)
-        h.set_params(raw)
-        h.set_streams(streams)
-        return h.log_likelihood(y), h
-
     def init(self, models, N, y1, seed, streams, key="main"):
         mid, raw = _rows(models)
         h = self._handle(key, mid, raw.shape[0], N, seed)
         h.set_params(raw)
         h.set_streams(streams)
         return h.init(y1), h
+
+    def log_likelihood(self, models, N, y, seed, streams, key="prop", skip=None):
+        """skip[m] = True: filter m is not run (proposal outside the prior's support, smc_samplers.jl:116); logZ = -inf"""
+        mid, raw = _rows(models)
+        h = self._handle(key, mid, raw.shape[0], N, seed)
+        h.set_params(raw)
+        h.set_streams(streams)
+        h.set_skip(skip if skip is not None and np.any(skip) else None)
+        out = h.log_likelihood(y)
+        h.set_skip(None)
+        return out, h
+
+    def rejuvenate(self, tmap, prior_spec, N, y, xi, chol, scales, filter_seeds, move_seed, streams, theta, logZ, main):
+        """rejuvenate! for this rank's parameter particles on the device (smc_pmmh_rejuvenate).
+        -> (theta, logZ, accepted, filters_run)"""
+        h = self._handle("prop", tmap.model_id, theta.shape[0], N, int(filter_seeds[0]))
+        h.set_streams(streams)
+        cfg = (id(tmap), id(prior_spec))
+        if getattr(h, "_pmmh_cfg", None) != cfg:
+            h.pmmh_configure(prior_spec[0], prior_spec[1], tmap.raw_from, tmap.raw_const)
+            h._pmmh_cfg = cfg
+        return h.pmmh_rejuvenate(main, y, xi, chol, scales, filter_seeds, move_seed, theta, logZ)
+
+    def release(self, h):
+        """close one handle (a superseded set of online filters, exchange!)"""
+        for k, v in list(self._handles.items()):
+            if v is h:
+                v.close()
+                del self._handles[k]
 
     def close(self):
         for h in self._handles.values():
@@ -75,10 +127,15 @@ class SMC:
     StateSpaceModel (the reference's closure smc.model(theta))."""
 
     def __init__(self, N, M, model, prior, chain, ess_threshold, min_ar=-1.0, seed=1, backend=None, comm=None,
-                 raw_fn=None):
-        """raw_fn (optional): vectorised shortcut for `model`: maps an [m, d_theta] array to (model_id, [m, n_raw]
-        parameter rows) without building m model objects per evaluation."""
+                 raw_fn=None, theta_map=None):
+        """theta_map (optional): ThetaMap, the device-evaluable form of `model`; with a prior of enumerated families it
+        moves rejuvenate! onto the device.  raw_fn (optional): vectorised shortcut for `model`: maps an [m, d_theta]
+        array to (model_id, [m, n_raw] parameter rows) without building m model objects per evaluation."""
         self.N, self.M, self.model, self.prior, self.chain = int(N), int(M), model, prior, int(chain)
+        self.theta_map = theta_map
+        if raw_fn is None and theta_map is not None:
+            def raw_fn(th, _t=theta_map):
+                return _t.model_id, _t.rows(th)
         self.raw_fn = raw_fn
         self.rng = np.random.default_rng(seed)
         self.seed = int(seed)
@@ -92,10 +149,14 @@ class SMC:
         self.ess_min = self.M * float(ess_threshold)
         self.acc_threshold, self.acc_ratio = float(min_ar), 0.0
         self.backend = backend if backend is not None else HipBackend()
+        self.prior_spec = prior.spec() if hasattr(prior, "spec") else None
+        self.device_pmmh = (theta_map is not None and self.prior_spec is not None and hasattr(self.backend, "rejuvenate")
+                            and self.theta.shape[1] == len(self.prior_spec[0]))
         self.comm = comm
         self.lo, self.hi = (0, self.M) if comm is None else comm.slice(self.M)
         self._calls = 0          # evaluation counter -> fresh Philox seed per batched evaluation
         self.psteps = 0          # executed inner particle-steps (all ranks), SURVEY 8(d)
+        self.psteps_skipped = 0  # particle-steps of proposals outside the prior's support: never run (smc_samplers.jl:116)
         self._main = None        # device handle of the online filters (smc2)
         self._theta_dev = None   # (handle, theta slice) whose parameter rows are on the device
         self.t = 0
@@ -117,12 +178,16 @@ class SMC:
             return RawModels(*self.raw_fn(np.asarray(thetas, dtype=np.float64)))
         return [self.model(th) for th in thetas]
 
-    def _filter_all(self, thetas, y, key="prop"):
-        """logZ[m] = log_likelihood(N, y, model(theta[m])) for every m: ONE batched GPU call per rank."""
+    def _filter_all(self, thetas, y, key="prop", skip=None):
+        """logZ[m] = log_likelihood(N, y, model(theta[m])) for every m: ONE batched GPU call per rank.
+        skip[m]: that filter is not run (its logZ reads -inf) and not counted."""
         models = self._models(thetas[self.lo:self.hi])
+        sk = None if skip is None else np.asarray(skip[self.lo:self.hi], dtype=bool)
         local, h = self.backend.log_likelihood(models, self.N, np.asarray(y, dtype=np.float64), self._next_seed(),
-                                               self._streams(), key=key)
-        self.psteps += self.M * self.N * len(y)
+                                               self._streams(), key=key, skip=sk)
+        nskip = 0 if skip is None else int(np.sum(skip))
+        self.psteps += (self.M - nskip) * self.N * len(y)
+        self.psteps_skipped += nskip * self.N * len(y)
         return self._gather(np.asarray(local)), h
 
     def __repr__(self):
@@ -162,24 +227,41 @@ def resample_(smc):
     return a
 
 
-def random_walk_kernel(theta):
-    """random_walk_kernel(theta::Vector{Vector{Float64}})   smc_samplers.jl:95-101
-    returns f(x, scale, rng) -> draw from MvNormal(x, scale * Sigma)."""
+def random_walk_factor(theta, scales):
+    """(L, s) such that the proposal of chain position c is  theta' = theta + sqrt(s[c]) * L z,  z ~ N(0, I):
+    multivariate theta (smc_samplers.jl:95-100): MvNormal(x, scale * Sigma), Sigma = 2.83^2/d * cov(theta) + 1e-10 I
+      (1e-2 I when the cloud has collapsed, norm(cov) < 1e-8)  ->  L = chol(Sigma), s = scales;
+    univariate theta (:87-92): Normal(x, scale * sigma) with sigma = 2.83^2 * var(theta) + 1e-10 (1e-2 when collapsed)
+      handed over as the STANDARD DEVIATION  ->  L = [[sigma]], s = scales^2  (sqrt(s) = scale)."""
     d = theta.shape[1]
+    scales = np.asarray(scales, dtype=np.float64)
     cov = np.atleast_2d(np.cov(theta.T))
+    if d == 1:
+        sigma = 1e-2 if np.linalg.norm(cov) < 1e-8 else 2.83 ** 2 * float(cov[0, 0]) + 1e-10
+        return np.array([[sigma]]), scales * scales
     if np.linalg.norm(cov) < 1e-8:
         sigma = 1e-2 * np.eye(d)
     else:
         sigma = (2.83 ** 2 / d) * cov + 1e-10 * np.eye(d)
-    L = np.linalg.cholesky(sigma)
+    return np.linalg.cholesky(sigma), scales
 
-    def kernel(x, scale, rng):                       # MvNormal(x, scale*Sigma)
-        return x + math.sqrt(scale) * (L @ rng.standard_normal(d))
 
-    def many(theta, scale, rng):
-        """one proposal per row of theta: the same normals, in the same order, as M calls of kernel()"""
-        z = rng.standard_normal((theta.shape[0], d))
-        return theta + math.sqrt(scale) * (z @ L.T)
+def random_walk_kernel(theta):
+    """random_walk_kernel(theta)   smc_samplers.jl:87-101
+    returns f(x, scale, rng) -> a draw of the reference's Normal(x, scale*sigma) / MvNormal(x, scale*Sigma)."""
+    d = theta.shape[1]
+    L, _ = random_walk_factor(theta, [1.0])            # fixed now: theta is updated in place during the chain
+
+    def eff(scale):
+        return scale * scale if d == 1 else scale
+
+    def kernel(x, scale, rng):
+        return x + math.sqrt(eff(scale)) * (L @ rng.standard_normal(d))
+
+    def many(th, scale, rng):
+        """one proposal per row of th: the same normals, in the same order, as M calls of kernel()"""
+        z = rng.standard_normal((th.shape[0], d))
+        return th + math.sqrt(eff(scale)) * (z @ L.T)
 
     kernel.many = many
     return kernel
@@ -187,12 +269,49 @@ def random_walk_kernel(theta):
 
 def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
     """rejuvenate!(smc, y, xi)   smc_samplers.jl:103-146 -- PMMH moves, `chain` per parameter particle.
-    All M proposals of one chain position are filtered in one batched call."""
+    On the device in one call per rank when the sampler has a ThetaMap and an enumerated prior; otherwise the
+    loop below with all M proposals of one chain position filtered in one batched call."""
+    y = np.asarray(y, dtype=np.float64)
+    if verbose:
+        out.write("\t[rejuvenating]")
+    if smc.device_pmmh:
+        accepted = _rejuvenate_device(smc, y, xi)
+    else:
+        accepted = _rejuvenate_host(smc, y, xi)
+    smc.omega = np.ones(smc.M)
+    smc.acc_ratio = float(accepted.sum()) / smc.M
+    if verbose:
+        out.write("\tacc_rate: %1.5f" % smc.acc_ratio)
+    return smc
+
+
+def _rejuvenate_device(smc, y, xi):
+    """The whole `for m ... for c in 1:chain` loop (smc_samplers.jl:112-138) in one smc_pmmh_rejuvenate call per rank;
+    the host contributes the random-walk factor (:95-100, from the full theta cloud every rank holds) and, with
+    sharded theta, ONE all-gather of the moved (theta, logZ, accepted) slices afterwards."""
+    L, s = random_walk_factor(smc.theta, 0.5 * np.arange(smc.chain, 0, -1))     # 0.5*reverse(1:chain)
+    seeds = np.array([smc._next_seed() for _ in range(smc.chain)], dtype=np.uint64)
+    move_seed = smc._next_seed()
+    lo, hi = smc.lo, smc.hi
+    th, lz, acc, nrun = smc.backend.rejuvenate(smc.theta_map, smc.prior_spec, smc.N, y, float(xi), L, s, seeds, move_seed,
+                                               smc._streams(), smc.theta[lo:hi], smc.logZ[lo:hi], smc._main)
+    d = smc.theta.shape[1]
+    packed = np.concatenate([np.asarray(th, dtype=np.float64).ravel(), lz, acc.astype(np.float64), [float(nrun)]])
+    allp = smc._gather(packed).reshape(-1, packed.size)
+    per = hi - lo
+    smc.theta = np.ascontiguousarray(allp[:, :per * d].reshape(-1, d))
+    smc.logZ = np.ascontiguousarray(allp[:, per * d:per * (d + 1)].ravel())
+    accepted = allp[:, per * (d + 1):per * (d + 2)].ravel() != 0.0
+    nrun_all = int(round(allp[:, -1].sum()))
+    smc.psteps += nrun_all * smc.N * len(y)
+    smc.psteps_skipped += (smc.M * smc.chain - nrun_all) * smc.N * len(y)
+    return accepted
+
+
+def _rejuvenate_host(smc, y, xi):
     kernel = random_walk_kernel(smc.theta)
     scales = 0.5 * np.arange(smc.chain, 0, -1)          # 0.5*reverse(1:chain)
     accepted = np.zeros(smc.M, dtype=bool)
-    if verbose:
-        out.write("\t[rejuvenating]")
     many = hasattr(smc.prior, "logpdf_many")
     for c in range(smc.chain):
         prop = kernel.many(smc.theta, scales[c], smc.rng)      # all M proposals of this chain position
@@ -204,9 +323,12 @@ def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
             ok = np.array([smc.prior.insupport(p) for p in prop])
             lp_prop = np.array([smc.prior.logpdf(p) if o else -math.inf for p, o in zip(prop, ok)])
             lp_cur = np.array([smc.prior.logpdf(q) for q in smc.theta])
-        safe = np.where(ok[:, None], prop, smc.theta)   # out-of-support proposals are never accepted
-        logZ_prop, hprop = smc._filter_all(safe, y)
-        acc_ratio = xi * (logZ_prop - smc.logZ) + (lp_prop - lp_cur)
+        # a proposal outside the support is never filtered (smc_samplers.jl:116): its slot is skipped on the device
+        # (the parameter row handed over for it is the current, valid theta; it is not read)
+        safe = np.where(ok[:, None], prop, smc.theta)
+        logZ_prop, hprop = smc._filter_all(safe, y, skip=~ok)
+        with np.errstate(invalid="ignore"):
+            acc_ratio = xi * (logZ_prop - smc.logZ) + (lp_prop - lp_cur)
         with np.errstate(divide="ignore"):
             acc = ok & (logZ_prop + lp_prop > -math.inf) & (np.log(u) < acc_ratio)
         smc.theta[acc] = prop[acc]
@@ -214,11 +336,7 @@ def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
         if smc._main is not None and acc[smc.lo:smc.hi].any():
             smc._main.copy_from(hprop, acc[smc.lo:smc.hi])      # x[m], w[m] <- x_prop, w_prop on the device
         accepted |= acc
-    smc.omega = np.ones(smc.M)
-    smc.acc_ratio = float(accepted.sum()) / smc.M
-    if verbose:
-        out.write("\tacc_rate: %1.5f" % smc.acc_ratio)
-    return smc
+    return accepted
 
 
 def density_tempered(smc, y, verbose=True, out=sys.stdout):
@@ -308,7 +426,10 @@ def _exchange(smc, y, verbose, out):
             new_logZ, h = smc.backend.log_likelihood(models, smc.N, y, smc._next_seed(), smc._streams(), key="main")
             new_logZ = smc._gather(np.asarray(new_logZ, dtype=np.float64))
             smc.psteps += smc.M * smc.N * len(y)
-            smc._main = h
+            old, smc._main = smc._main, h
+            smc._theta_dev = None
+            if old is not None and old is not h and hasattr(smc.backend, "release"):
+                smc.backend.release(old)          # the superseded N-particle filters
             _, smc.omega, smc.ess = _reweight(np.asarray(new_logZ) - smc.logZ)
             smc.logZ = np.asarray(new_logZ, dtype=np.float64).copy()
         else:

@@ -63,11 +63,58 @@ class OracleHandle:
 class OracleBackend:
     def __init__(self, seg=0, resampler="multinomial"):
         self.seg, self.systematic = seg, resampler == "systematic"
+        self.filters_run = 0
 
-    def log_likelihood(self, models, N, y, seed, streams, key="prop"):
+    def log_likelihood(self, models, N, y, seed, streams, key="prop", skip=None):
         mid, raw = params_matrix(models)
         h = OracleHandle(mid, raw, N, self.seg, seed, streams, self.systematic)
-        return h.log_likelihood(np.asarray(y, dtype=np.float64)), h
+        y = np.asarray(y, dtype=np.float64)
+        if skip is None or not np.any(skip):
+            self.filters_run += h.n_theta
+            return h.log_likelihood(y), h
+        # skipped filters are never run (smc_samplers.jl:116): logZ = -inf
+        self.filters_run += int(h.n_theta - np.sum(skip))
+        return np.array([-np.inf if skip[m] else f.log_likelihood(y) for m, f in enumerate(h.f)]), h
+
+    def rejuvenate(self, tmap, prior_spec, N, y, xi, chol, scales, filter_seeds, move_seed, streams, theta, logZ, main):
+        """rejuvenate!(smc, y, xi) (smc_samplers.jl:103-146) for the parameter particles of one rank, statement by
+        statement with the oracle's pieces; the twin of smc_pmmh_rejuvenate.  -> (theta, logZ, accepted, filters_run)"""
+        fam, par = prior_spec
+        theta = np.array(theta, dtype=np.float64)
+        logZ = np.array(logZ, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        M, d = theta.shape
+        accepted = np.zeros(M, dtype=bool)
+        nrun = 0
+        for c in range(len(scales)):                                    # for c in 1:smc.chain        :113
+            for m in range(M):                                          # (Threads.@threads for m     :112)
+                st = int(streams[m])
+                prop = ob.pmmh_propose(move_seed, st, c, theta[m], chol, scales[c])               # :114
+                if not all(ob.prior_insupport(fam[i], par[i], prop[i]) for i in range(d)):       # :116
+                    continue
+                raw = tmap.rows(prop[None, :])[0]                                                  # smc.model(theta_prop)
+                f = ob.Filter(tmap.model_id, raw, N, seg=self.seg, seed=int(filter_seeds[c]), stream=st, systematic=self.systematic)
+                logZ_prop = f.log_likelihood(y)                                                    # :117-121
+                nrun += 1
+                lp_prop = lp_cur = 0.0
+                for i in range(d):
+                    lp_prop = lp_prop + ob.prior_logpdf(fam[i], par[i], prop[i])
+                    lp_cur = lp_cur + ob.prior_logpdf(fam[i], par[i], theta[m, i])
+                prior_ratio = lp_prop - lp_cur                                                     # :123
+                likelihood_ratio = xi * (logZ_prop - logZ[m])                                      # :124
+                log_post_prop = logZ_prop + lp_prop                                                # :126
+                acc_ratio = likelihood_ratio + prior_ratio                                         # :127
+                if log_post_prop > -np.inf and ob.pmmh_log_uniform(move_seed, st, c) < acc_ratio:  # :129
+                    logZ[m] = logZ_prop                                                            # :130
+                    theta[m] = prop                                                                # :131
+                    if main is not None:
+                        main.f[m].copy_state_from(f)                                               # :132-133
+                    accepted[m] = True                                                             # :135
+        self.filters_run += nrun
+        return theta, logZ, accepted, nrun
+
+    def release(self, h):
+        pass
 
     def init(self, models, N, y1, seed, streams, key="main"):
         mid, raw = params_matrix(models)

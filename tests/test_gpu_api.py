@@ -7,7 +7,7 @@ import pytest
 
 import sequential_monte_carlo_amd as smc
 from oracle_backend import OracleBackend
-from test_samplers_cpu import LG, lg_mod, lg_prior
+from test_samplers_cpu import LG, LG_TMAP, lg_mod, lg_prior
 
 pytestmark = pytest.mark.gpu
 
@@ -65,9 +65,10 @@ def test_batched_models_and_ucsv_shapes(ob):
     assert a.min() >= 0 and a.max() <= 99 and abs(a.mean() - np.sum(np.arange(100) * ww)) < 2.0
 
 
-def _run(backend, online):
+def _run(backend, online, device=False, min_ar=-1.0):
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 24, seed=1998)
-    s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, seed=7, backend=backend)
+    s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, min_ar=min_ar, seed=7, backend=backend, theta_map=LG_TMAP if device else None)
+    assert s.device_pmmh == device
     buf = io.StringIO()
     if online:
         smc.smc2(s, y)
@@ -79,12 +80,16 @@ def _run(backend, online):
     return s, buf.getvalue(), stages, None
 
 
-def test_density_tempered_hip_equals_oracle_backend():
-    sh, th, stg_h, _ = _run(smc.smc_samplers.HipBackend(), online=False)
-    so, to, stg_o, _ = _run(OracleBackend(), online=False)
-    assert th == to and stg_h == stg_o
+@pytest.mark.parametrize("device", [False, True])
+def test_density_tempered_hip_equals_oracle_backend(device):
+    """device=True: rejuvenate! runs in smc_pmmh_rejuvenate (proposals, prior, accept test, overwrite on the GPU)
+    and must reproduce the oracle's statement-by-statement loop bit for bit: theta, logZ, acceptance rates, ladder."""
+    sh, th, stg_h, _ = _run(smc.smc_samplers.HipBackend(), online=False, device=device)
+    so, to, stg_o, _ = _run(OracleBackend(), online=False, device=device)
+    assert th == to and stg_h == stg_o and "acc_rate" in th
     assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
-    assert np.array_equal(bits(sh.omega), bits(so.omega)) and sh.psteps == so.psteps
+    assert np.array_equal(bits(sh.omega), bits(so.omega)) and sh.psteps == so.psteps and sh.psteps_skipped == so.psteps_skipped
+    assert sh.psteps_skipped > 0 and sh.psteps == so.backend.filters_run * 256 * 24
 
 
 def ucsv_mod(theta):
@@ -97,10 +102,15 @@ def ucsv_prior():
     return smc.product_distribution([smc.Uniform(0.0, 1.0), smc.Normal(3.0, 2.0), smc.Uniform(0.0, 2.0), smc.Uniform(0.0, 2.0)])
 
 
-def _run_ucsv(backend, online=False):
+UCSV_TMAP = smc.ThetaMap(3, [0, 0, 1, 2, 3], [0.0] * 5)
+
+
+def _run_ucsv(backend, online=False, device=False):
     u = smc.UCSV((0.2, 0.2), 3.0, (0.0, 0.0))
     _, y = smc.simulate(u, 20, seed=1998)
-    s = smc.SMC(256, 24, ucsv_mod, ucsv_prior(), 2, 0.7 if online else 0.5, seed=3, backend=backend)
+    s = smc.SMC(256, 24, ucsv_mod, ucsv_prior(), 2, 0.7 if online else 0.5, seed=3, backend=backend,
+                theta_map=UCSV_TMAP if device else None)
+    assert s.device_pmmh == device
     buf = io.StringIO()
     if online:
         smc.smc2(s, y)
@@ -112,21 +122,23 @@ def _run_ucsv(backend, online=False):
     return s, buf.getvalue(), stages, None
 
 
-def test_density_tempered_ucsv_hip_equals_oracle_backend():
+@pytest.mark.parametrize("device", [False, True])
+def test_density_tempered_ucsv_hip_equals_oracle_backend(device):
     """BASELINE configs[4] at a size the oracle finishes in seconds: density_tempered (smc_samplers.jl:222-281)
     over the UCSV model with the example's prior U(0,1) x N(3,2) x U(0,2) x U(0,2); every proposal outside the
     prior's support is skipped like the reference does (:116)."""
-    sh, th, stg_h, _ = _run_ucsv(smc.smc_samplers.HipBackend())
-    so, to, stg_o, _ = _run_ucsv(OracleBackend())
+    sh, th, stg_h, _ = _run_ucsv(smc.smc_samplers.HipBackend(), device=device)
+    so, to, stg_o, _ = _run_ucsv(OracleBackend(), device=device)
     assert th == to and stg_h == stg_o and len(stg_h) >= 2
     assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
     assert np.array_equal(bits(sh.omega), bits(so.omega)) and sh.psteps == so.psteps
     assert np.all(sh.theta[:, 0] > 0) and np.all(sh.theta[:, 0] < 1)          # never left the prior's support
 
 
-def test_smc2_online_ucsv_hip_equals_oracle_backend():
-    sh, th, xh, wh = _run_ucsv(smc.smc_samplers.HipBackend(), online=True)
-    so, to, xo, wo = _run_ucsv(OracleBackend(), online=True)
+@pytest.mark.parametrize("device", [False, True])
+def test_smc2_online_ucsv_hip_equals_oracle_backend(device):
+    sh, th, xh, wh = _run_ucsv(smc.smc_samplers.HipBackend(), online=True, device=device)
+    so, to, xo, wo = _run_ucsv(OracleBackend(), online=True, device=device)
     assert th == to and "[rejuvenating]" in th
     assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
     assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo))
@@ -145,13 +157,52 @@ def test_samplers_with_systematic_resampling_option():
     assert not np.array_equal(bits(sh.logZ), bits(sm.logZ))          # and it is a different sampler than the default
 
 
-def test_smc2_online_hip_equals_oracle_backend():
-    """smc² / smc²! incl. resample!(permute), PMMH accept (copy_from) on the device."""
-    sh, th, xh, wh = _run(smc.smc_samplers.HipBackend(), online=True)
-    so, to, xo, wo = _run(OracleBackend(), online=True)
+@pytest.mark.parametrize("device", [False, True])
+def test_smc2_online_hip_equals_oracle_backend(device):
+    """smc² / smc²! incl. resample!(permute), PMMH accept (copy of the accepted x, w clouds) on the device."""
+    sh, th, xh, wh = _run(smc.smc_samplers.HipBackend(), online=True, device=device)
+    so, to, xo, wo = _run(OracleBackend(), online=True, device=device)
     assert th == to and "[rejuvenating]" in th
     assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+    assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo)) and sh.psteps == so.psteps
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_exchange_on_gpu_equals_oracle_backend(device):
+    """exchange! (smc_samplers.jl:163-189): min_ar above any acceptance ratio doubles the state particles after the
+    first rejuvenation; the online filters are re-created with 2N particles on the GPU."""
+    sh, th, xh, wh = _run(smc.smc_samplers.HipBackend(), online=True, device=device, min_ar=2.0)
+    so, to, xo, wo = _run(OracleBackend(), online=True, device=device, min_ar=2.0)
+    assert th == to and "particles added" in th and sh.N == so.N > 256 and sh._main.n_x == sh.N
+    assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+    assert np.array_equal(bits(sh.omega), bits(so.omega))
     assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo))
+    assert len(sh.backend._handles) <= 3          # the superseded filter sets were released
+
+
+def test_skipped_filters_are_not_run(ob):
+    """smc_set_skip: the marked filters are left out of log_likelihood (logZ = -inf, state untouched), the others
+    are bit-identical to a run without the mask; resident and step kernels."""
+    from sequential_monte_carlo_amd import _lib as L
+    raw = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0]
+    _, y = ob.simulate(1, raw, 12, 3)
+    for n, seg, fl in ((1024, 0, 0), (1024, 0, L.FLAG_NO_RESIDENT), (3000, 1024, 0)):
+        h = L.Handle(1, 5, n, seg=seg, seed=8, flags=fl)
+        h.set_params(np.tile(raw, (5, 1)))
+        z0 = h.log_likelihood(y)
+        x0, w0, _ = h.state(want_anc=False)
+        h.reseed(9)
+        h.set_skip([0, 1, 0, 1, 1])
+        z1 = h.log_likelihood(y)
+        x1, w1, _ = h.state(want_anc=False)
+        h.set_skip(None)
+        h.reseed(9)
+        z2 = h.log_likelihood(y)
+        x2, _, _ = h.state(want_anc=False)
+        assert np.all(z1[[1, 3, 4]] == -np.inf) and np.array_equal(bits(z1[[0, 2]]), bits(z2[[0, 2]])) and np.all(np.isfinite(z2))
+        assert np.array_equal(bits(x1[:, [1, 3, 4]]), bits(x0[:, [1, 3, 4]]))          # skipped slots keep their old state
+        assert np.array_equal(bits(x1[:, [0, 2]]), bits(x2[:, [0, 2]]))
+        h.close()
 
 
 def test_batched_kalman_on_device(ob):

@@ -55,9 +55,16 @@ def test_models_and_simulate():
         smc.StochasticVolatility(0, 1.5, 1)
 
 
-def run_dt(M=32, N=128, T=25, seed=3, comm=None):
+LG_TMAP = smc.ThetaMap(1, [0, -1, 1, 2, -1, -1], [0.0, 1.0, 0.0, 0.0, 0.0, 1.0])    # lg_mod in device-evaluable form
+
+
+def run_dt(M=32, N=128, T=25, seed=3, comm=None, device=False):
+    """device=True: the sampler gets a ThetaMap, i.e. rejuvenate! takes the one-call-per-rank path (on the GPU:
+    smc_pmmh_rejuvenate; here its oracle twin); False: the host loop with numpy random numbers."""
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
-    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm)
+    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm,
+                theta_map=LG_TMAP if device else None)
+    assert s.device_pmmh == device
     buf = io.StringIO()
     stages = smc.density_tempered(s, y, verbose=True, out=buf)
     return s, stages, buf.getvalue()
@@ -74,9 +81,99 @@ def test_density_tempered_ladder():
     assert text.startswith("ξ = ") and "[rejuvenating]" in text and "acc_rate: " in text    # reference's log format
     th = smc.expected_parameters(s)
     assert -1 < th[0] < 1 and th[1] > 0 and th[2] > 0
-    assert s.psteps == (1 + 2 * (len(stages) - 1)) * 32 * 128 * 25
+    # every executed filter is counted, every proposal outside the prior's support is skipped (smc_samplers.jl:116)
+    assert s.psteps + s.psteps_skipped == (1 + 2 * (len(stages) - 1)) * 32 * 128 * 25
+    assert s.psteps == s.backend.filters_run * 128 * 25 and s.psteps_skipped > 0
     s2, stages2, _ = run_dt()
     assert np.array_equal(s.theta, s2.theta) and np.array_equal(s.logZ, s2.logZ)      # deterministic
+
+
+def test_density_tempered_device_style_rejuvenation():
+    """The ThetaMap path (one rejuvenate call per rank, Philox-keyed proposals and accept uniforms): same ladder
+    properties, executed filters counted exactly, deterministic."""
+    s, stages, text = run_dt(device=True)
+    xis = [st[0] for st in stages]
+    assert xis[-1] == 1.0 and all(b > a for a, b in zip(xis, xis[1:])) and len(xis) >= 2
+    for xi, ess, acc in stages[:-1]:
+        assert abs(ess - s.ess_min) < 0.5 and 0.0 < acc <= 1.0
+    assert "[rejuvenating]" in text and "acc_rate: " in text
+    assert s.psteps + s.psteps_skipped == (1 + 2 * (len(stages) - 1)) * 32 * 128 * 25
+    assert s.psteps == s.backend.filters_run * 128 * 25 and s.psteps_skipped > 0
+    th = smc.expected_parameters(s)
+    assert -1 < th[0] < 1 and th[1] > 0 and th[2] > 0 and lg_prior().insupport_many(s.theta).all()
+    s2, _, _ = run_dt(device=True)
+    assert np.array_equal(s.theta, s2.theta) and np.array_equal(s.logZ, s2.logZ)
+
+
+def test_pmmh_pieces_host_library_equals_oracle(L, ob):
+    """The spec's PMMH pieces as compiled into libsmchip.so (host build of csrc/smc_spec.h) against the oracle's
+    independent C restatement: proposals, log-uniforms, prior log densities - bit for bit."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    lib = L.lib()
+    dp = C.POINTER(C.c_double)
+    for d in (1, 2, 3, 4, 7, 8):
+        A = rng.normal(size=(d, d))
+        chol = np.linalg.cholesky(A @ A.T + 0.1 * np.eye(d))
+        th = rng.normal(size=d)
+        for c in (0, 1, 5):
+            out = np.zeros(d)
+            assert lib.smc_host_pmmh_propose(d, 12345 + d, 77, c, th.ctypes.data_as(dp), chol.ctypes.data_as(dp), 1.5, out.ctypes.data_as(dp)) == 0
+            assert np.array_equal(out.view(np.uint64), ob.pmmh_propose(12345 + d, 77, c, th, chol, 1.5).view(np.uint64))
+            assert lib.smc_host_pmmh_log_uniform(99, d, c) == ob.pmmh_log_uniform(99, d, c) <= 0.0
+    fams = lg_prior().spec()
+    u = smc.product_distribution([smc.Uniform(0, 1), smc.Normal(3, 2), smc.Uniform(0, 2), smc.Uniform(0, 2)]).spec()
+    for fam, par in list(zip(*fams)) + list(zip(*u)):
+        for x in np.concatenate([rng.normal(size=200) * 2, [0.0, 1.0, -1.0, 2.0, np.inf, -np.inf]]):
+            a = lib.smc_host_prior_logpdf(int(fam), par.ctypes.data_as(dp), float(x))
+            b = ob.prior_logpdf(fam, par, x)
+            assert (a == b) or (np.isnan(a) and np.isnan(b)), (fam, x, a, b)
+    # and the numbers are the densities they claim to be
+    from scipy.stats import lognorm, norm, truncnorm, uniform
+    assert ob.prior_logpdf(*[f[0] for f in fams], 0.3) == pytest.approx(truncnorm(-1, 1).logpdf(0.3), rel=1e-13)
+    assert ob.prior_logpdf(fams[0][1], fams[1][1], 1.7) == pytest.approx(lognorm(1).logpdf(1.7), rel=1e-13)
+    assert ob.prior_logpdf(u[0][1], u[1][1], 2.2) == pytest.approx(norm(3, 2).logpdf(2.2), rel=1e-13)
+    assert ob.prior_logpdf(u[0][2], u[1][2], 1.2) == pytest.approx(uniform(0, 2).logpdf(1.2), rel=1e-13)
+    assert ob.prior_logpdf(u[0][2], u[1][2], 2.2) == -np.inf
+
+
+def test_random_walk_factor_follows_both_reference_kernels():
+    """smc_samplers.jl:87-92 (univariate: Normal(x, scale*sigma), a standard deviation) and :95-100 (MvNormal(x, scale*Sigma))"""
+    from sequential_monte_carlo_amd.smc_samplers import random_walk_factor
+    rng = np.random.default_rng(1)
+    th1 = rng.normal(size=(200, 1)) * 0.3
+    L, s = random_walk_factor(th1, [1.5, 1.0, 0.5])
+    sigma = 2.83 ** 2 * np.var(th1[:, 0], ddof=1) + 1e-10
+    assert L.shape == (1, 1) and L[0, 0] == pytest.approx(sigma) and np.allclose(np.sqrt(s) * L[0, 0], np.array([1.5, 1.0, 0.5]) * sigma)
+    th3 = rng.normal(size=(300, 3))
+    L, s = random_walk_factor(th3, [1.5, 1.0])
+    assert np.allclose(L @ L.T, 2.83 ** 2 / 3 * np.cov(th3.T) + 1e-10 * np.eye(3)) and np.array_equal(s, [1.5, 1.0])
+    L, _ = random_walk_factor(np.ones((50, 2)), [1.0])
+    assert np.allclose(L @ L.T, 1e-2 * np.eye(2))
+
+
+def test_exchange_doubles_state_particles():
+    """exchange! (smc_samplers.jl:163-189): with min_ar above the acceptance ratio the number of state particles
+    doubles after a rejuvenation, the online filters are re-run over y[1:t-1] with 2N particles and the outer
+    weights become the ratio of the new and old likelihood estimates."""
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 30, seed=1998)
+    for device in (False, True):
+        s = smc.SMC(64, 24, lg_mod, lg_prior(), 2, 0.5, min_ar=2.0, seed=5, backend=OracleBackend(),
+                    theta_map=LG_TMAP if device else None)
+        smc.smc2(s, y)
+        buf = io.StringIO()
+        grown = []
+        for t in range(2, 31):
+            n0, logZ0 = s.N, s.logZ.copy()
+            smc.smc2_step(s, y, t, verbose=True, out=buf)
+            if s.N != n0:
+                grown.append((t, n0, s.N))
+                assert s._main.N == s.N and s._main.f[0].n == s.N
+        assert grown and all(b == 2 * a for _, a, b in grown) and s.N == 64 * 2 ** len(grown)
+        assert "%d particles added" % grown[0][2] in buf.getvalue()
+        assert abs(s.omega.sum() - 1) < 1e-12 and np.all(np.isfinite(s.logZ))
+        x, w, _ = s._main.state()
+        assert x.shape == (1, 24, s.N) and np.allclose(w.sum(axis=1), 1.0, atol=1e-12)
 
 
 def test_smc2_online_runs_and_tracks():
@@ -98,9 +195,10 @@ def test_smc2_online_runs_and_tracks():
     assert -1 < th[0] < 1 and th[1] > 0 and th[2] > 0
 
 
-def run_online(M=24, N=64, T=30, seed=5, comm=None):
+def run_online(M=24, N=64, T=30, seed=5, comm=None, device=False):
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
-    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm)
+    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm,
+                theta_map=LG_TMAP if device else None)
     smc.smc2(s, y)
     moves = 0
     for t in range(2, T + 1):
@@ -119,13 +217,15 @@ import sequential_monte_carlo_amd as smc
 from sequential_monte_carlo_amd.distributed import ThetaComm
 from test_samplers_cpu import run_dt, run_online
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
-s, stages, text = run_dt(comm=ThetaComm(dist))
-assert (s.lo, s.hi) == ((0, 16) if dist.get_rank() == 0 else (16, 32))
-np.save(sys.argv[4] + ".%d.npy" % dist.get_rank(), np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages]]))
-# online SMC^2 with theta sharded: resample! moves whole filters between the two ranks (all-to-all)
-so, moves, x, w = run_online(comm=ThetaComm(dist))
-assert moves >= 1
-np.save(sys.argv[4] + ".online.%d.npy" % dist.get_rank(), np.concatenate([so.theta.ravel(), so.logZ, so.omega, x.ravel(), w.ravel()]))
+for device in (False, True):      # host-loop rejuvenation / one-call-per-rank rejuvenation (ThetaMap)
+    tag = sys.argv[4] + (".dev" if device else "")
+    s, stages, text = run_dt(comm=ThetaComm(dist), device=device)
+    assert (s.lo, s.hi) == ((0, 16) if dist.get_rank() == 0 else (16, 32))
+    np.save(tag + ".%d.npy" % dist.get_rank(), np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]]))
+    # online SMC^2 with theta sharded: resample! moves whole filters between the two ranks (all-to-all)
+    so, moves, x, w = run_online(comm=ThetaComm(dist), device=device)
+    assert moves >= 1
+    np.save(tag + ".online.%d.npy" % dist.get_rank(), np.concatenate([so.theta.ravel(), so.logZ, so.omega, x.ravel(), w.ravel()]))
 dist.destroy_process_group()
 '''
 
@@ -133,8 +233,6 @@ dist.destroy_process_group()
 def test_theta_sharding_world_size_2_gloo(tmp_path):
     """N > 1 path: two gloo ranks each filter half of theta and all-gather logZ; the result is
     identical on both ranks and identical to the single-process run (stream id = global theta index)."""
-    s, stages, _ = run_dt()
-    ref = np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages]])
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = str(29500 + (os.getpid() % 2000))
@@ -143,17 +241,21 @@ def test_theta_sharding_world_size_2_gloo(tmp_path):
              for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0
-    for r in range(2):
-        got = np.load(str(tmp_path / "out") + ".%d.npy" % r)
-        assert np.array_equal(got, ref)
-    # online SMC^2: the two halves of the filter states, concatenated, equal the single-process run
-    so, moves, x, w = run_online()
-    assert moves >= 1
-    head = np.concatenate([so.theta.ravel(), so.logZ, so.omega])
-    parts = [np.load(str(tmp_path / "out") + ".online.%d.npy" % r) for r in range(2)]
-    for p_ in parts:
-        assert np.array_equal(p_[:head.size], head)
-    d, M, N = x.shape[0], x.shape[1], x.shape[2]
-    xs = np.concatenate([p_[head.size:head.size + d * (M // 2) * N].reshape(d, M // 2, N) for p_ in parts], axis=1)
-    ws = np.concatenate([p_[head.size + d * (M // 2) * N:].reshape(M // 2, N) for p_ in parts], axis=0)
-    assert np.array_equal(xs, x) and np.array_equal(ws, w)
+    for device in (False, True):
+        tag = str(tmp_path / "out") + (".dev" if device else "")
+        s, stages, _ = run_dt(device=device)
+        ref = np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]])
+        for r in range(2):
+            got = np.load(tag + ".%d.npy" % r)
+            assert np.array_equal(got, ref), device
+        # online SMC^2: the two halves of the filter states, concatenated, equal the single-process run
+        so, moves, x, w = run_online(device=device)
+        assert moves >= 1
+        head = np.concatenate([so.theta.ravel(), so.logZ, so.omega])
+        parts = [np.load(tag + ".online.%d.npy" % r) for r in range(2)]
+        for p_ in parts:
+            assert np.array_equal(p_[:head.size], head), device
+        d, M, N = x.shape[0], x.shape[1], x.shape[2]
+        xs = np.concatenate([p_[head.size:head.size + d * (M // 2) * N].reshape(d, M // 2, N) for p_ in parts], axis=1)
+        ws = np.concatenate([p_[head.size + d * (M // 2) * N:].reshape(M // 2, N) for p_ in parts], axis=0)
+        assert np.array_equal(xs, x) and np.array_equal(ws, w), device
