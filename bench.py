@@ -175,6 +175,8 @@ def main(argv=None):
     if ctx.rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
+    if getattr(ctx, "aux_stalled", False):
+        os._exit(0)          # the helper thread sits in a collective: no orderly teardown, the line is out
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()
 
@@ -471,6 +473,3 @@ def bench_sampler(args, ctx, algo, scaling, steps, warmup):
 
 if __name__ == "__main__":
     main()
-    sys.stdout.flush()
-    if threading.active_count() > 1:     # a stalled aux thread must not keep the rank alive
-        os._exit(0)

@@ -114,3 +114,21 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, fn)).read()
                 assert "oracle" not in src.replace("the oracle", "").replace("oracle's", "").replace(
                     "vs oracle", "").replace("against the oracle", ""), fn
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` without torch.distributed.run: the launcher process starts two fresh ranks
+    (before anything touches a GPU), they form a gloo group, and rank 0's JSON line comes back through the parent."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--dry-launch"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line == {"dry_launch": True, "n_gpus": 2, "ranks_seen": 2, "dist_backend": "gloo"}
+    # a failing rank makes the launcher fail (bad flag -> argparse exits 2 in every rank)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "nope"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode != 0
