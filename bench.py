@@ -75,6 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="sampler workloads: weak = 512 parameter particles per GPU; strong = --n-theta in total")
     ap.add_argument("--n-theta", type=int, default=4096, help="total parameter particles of a strong-scaling sampler run")
+    ap.add_argument("--window", type=int, default=8, help="smc2: propagation steps per device call (smc2_run); 1 = one smc2! per call")
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the strong-scaling sampler runs appended to a filter workload's line")
@@ -433,13 +434,11 @@ def bench_sampler(args, ctx, algo, scaling, steps, warmup):
         if algo in ("dt", "c5dt"):
             stages = smc.density_tempered(s, y, verbose=False, out=io.StringIO())
         else:
-            sink = io.StringIO()
             smc.smc2(s, y)
-            stages = []
-            for t in range(2, T + 1):
-                if s.ess < s.ess_min:
-                    stages.append(t)            # a resample-move happens inside this step
-                smc.smc2_step(s, y, t, verbose=False, out=sink)
+            calls = s._calls
+            # `for t in 2:T smc²!(smc,y,t) end` (smc_samplers.jl:308-340), several propagation steps per device call
+            smc.smc2_run(s, y, 2, T, window=args.window, verbose=False)
+            stages = [0] * ((s._calls - calls) // (chain + 1 if s.device_pmmh else chain))     # resample-move rounds
         return s, stages
 
     for k in range(warmup):

@@ -65,6 +65,14 @@ int smc_reseed(smc_handle h, uint64_t seed);
 int smc_init(smc_handle h, double y1, double* logmu /*[n_theta]*/);
 /* bootstrap_filter!(x, w, y, model) -> (logmu, w, ess)      src/particles.jl:107-129 */
 int smc_step(smc_handle h, double y_t, double* logmu /*[n_theta]*/, double* ess /*[n_theta] or NULL*/);
+/* k consecutive bootstrap_filter! calls (the loop `for t in 2:T smc²!(smc,y,t)` of the online sampler,
+ * src/smc_samplers.jl:325-335, between two resample-move decisions) in ONE launch with the clouds resident in LDS:
+ * returns (logmu, ess) of every step, [k][n_theta] each, but does NOT advance the filters - the caller looks at the
+ * k outer ESS values and then keeps the first j steps with smc_step_commit(h, j) (j < k re-runs those j steps: the
+ * random numbers are counter based, the bits are the same; j = 0 keeps nothing).  Bit-identical to k (or j) smc_step
+ * calls.  Needs single-segment filters that fit the LDS-resident kernel (n_x <= 8192); k <= 64. */
+int smc_step_window(smc_handle h, const double* y /*[k]*/, int k, double* logmu /*[k][n_theta]*/, double* ess /*[k][n_theta] or NULL*/);
+int smc_step_commit(smc_handle h, int j);
 /* log_likelihood(N, y, model) -> (x, w, logZ)               src/particles.jl:132-147
  * logmu_trace / ess_trace: [T][n_theta] or NULL. */
 int smc_log_likelihood(smc_handle h, const double* y, int64_t T, double* logZ /*[n_theta]*/,

@@ -22,7 +22,7 @@ EXPORTS = [
     "smc_model_nraw", "smc_auto_seg", "smc_device_count", "smc_host_exp", "smc_host_log", "smc_host_philox4x32_10",
     "smc_host_box_muller", "smc_sys_targets", "smc_device_math", "smc_last_error", "smc_version",
     "smc_set_skip", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_host_pmmh_propose", "smc_host_pmmh_log_uniform",
-    "smc_host_prior_logpdf",
+    "smc_host_prior_logpdf", "smc_step_window", "smc_step_commit",
 ]
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
 
@@ -111,6 +111,8 @@ def lib():
     L.smc_host_box_muller.restype = None
     L.smc_host_box_muller.argtypes = [_u32p, _dp, _dp]
     L.smc_device_math.argtypes = [C.c_int, _dp, _dp, C.c_int64, _dp, C.c_int]
+    L.smc_step_window.argtypes = [h, _dp, C.c_int, _dp, _dp]
+    L.smc_step_commit.argtypes = [h, C.c_int]
     L.smc_set_skip.argtypes = [h, C.POINTER(C.c_uint8)]
     L.smc_pmmh_configure.argtypes = [h, C.c_int, _i32p, _dp, _i32p, _dp]
     L.smc_pmmh_rejuvenate.argtypes = [h, h, _dp, C.c_int64, C.c_double, _dp, _dp, C.c_int, _u64p, C.c_uint64, _dp, _dp,
@@ -235,6 +237,22 @@ class Handle:
         ess = np.zeros(self.n_theta)
         check(lib().smc_step(self._h, float(y), _d(lm), _d(ess)))
         return lm, ess
+
+    def step_window(self, y):
+        """len(y) bootstrap_filter! steps in one launch, not yet kept: ([k][n_theta] logmu, [k][n_theta] ess);
+        follow with step_commit(j)."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        lm = np.zeros((y.size, self.n_theta))
+        ess = np.zeros((y.size, self.n_theta))
+        check(lib().smc_step_window(self._h, _d(y), y.size, _d(lm), _d(ess)))
+        return lm, ess
+
+    def step_commit(self, j):
+        check(lib().smc_step_commit(self._h, int(j)))
+
+    @property
+    def can_window(self):
+        return self.nseg == 1 and self.resident
 
     def log_likelihood(self, y, trace=False):
         y = np.ascontiguousarray(y, dtype=np.float64)

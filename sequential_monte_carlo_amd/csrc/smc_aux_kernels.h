@@ -2,6 +2,7 @@
 // normalize / resample).  Included by smc_capi.hip only.
 #pragma once
 #include "smc_kernels.h"
+#include "smc_resident.h"
 
 namespace smc {
 
@@ -299,6 +300,30 @@ __global__ void k_copy_slots(FilterView dst, int dcur, FilterView src, int scur,
     }
 }
 
+// Keeps the first j steps of a window whose k_resident<WIN> launch ran exactly j steps: logZ += logmu_1 + .. + logmu_j in
+// step order (the same additions smc_step makes), and the "last emitted" values become those of step j.  grid over theta.
+__global__ void k_commit(FilterView v, int j, const StepRec* recs /*[ntheta][j]*/) {
+    const int th = blockIdx.x * blockDim.x + threadIdx.x;
+    if (th >= v.ntheta) return;
+    double z = v.logZ[th], logmu = 0.0, ess = 0.0;
+    StepRec o{};
+    for (int t = 0; t < j; ++t) {
+        o = recs[(size_t)th * j + t];
+        combine_outputs(o.kb, o.S, seg_R(o.hi, o.lo, 0, 0), 0, v.n, logmu, ess);
+        z = z + logmu;
+    }
+    v.logZ[th] = z;
+    v.last_logmu[th] = logmu;
+    v.last_ess[th] = ess;
+    v.last_K[th] = o.kb;
+    v.last_D[th] = o.S;
+    if (v.host_out) {
+        v.host_out[th] = z;
+        v.host_out[(size_t)v.ntheta + th] = logmu;
+        v.host_out[2 * (size_t)v.ntheta + th] = ess;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // PMMH rejuvenation on the device (rejuvenate!, smc_samplers.jl:103-146): one lane per parameter particle.
 //   k_pmmh_propose  theta' ~ MvNormal(theta, scale Sigma) (:114), insupport (:116), prior logpdfs (:123), and the
@@ -317,6 +342,8 @@ struct PmmhDev {
     unsigned char* any;   // [ntheta] accepted at least once in this rejuvenation (acc_array, :135)
     unsigned long long* nrun;   // [1] proposal filters executed so far
     double* chol;         // [d][d] lower Cholesky factor of the random-walk covariance (:95-100)
+    int32_t* order;       // [ntheta] the filters of this chain position, those to run first (FilterView::order)
+    int32_t* counts;      // [2] how many are to run / skipped (filled by k_pmmh_propose, cleared by k_pmmh_accept)
 };
 __global__ void k_pmmh_propose(FilterView v, PmmhSpec s, PmmhDev p, int model, uint64_t move_seed, uint32_t c, double sq, Params* params) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,6 +354,9 @@ __global__ void k_pmmh_propose(FilterView v, PmmhSpec s, PmmhDev p, int model, u
     const bool ok = pmmh_insupport(s, pr);
     p.skip[m] = ok ? 0 : 1;
     for (int i = 0; i < s.d; ++i) p.prop[(size_t)m * MAX_DTHETA + i] = pr[i];
+    // which workgroup runs which filter does not matter for the results: any order of the two groups will do
+    if (ok) p.order[atomicAdd(&p.counts[0], 1)] = m;
+    else p.order[v.ntheta - 1 - atomicAdd(&p.counts[1], 1)] = m;
     if (!ok) return;
     p.lp[2 * (size_t)m] = pmmh_logprior(s, pr);
     p.lp[2 * (size_t)m + 1] = pmmh_logprior(s, th);
@@ -338,6 +368,7 @@ __global__ void k_pmmh_propose(FilterView v, PmmhSpec s, PmmhDev p, int model, u
 __global__ void k_pmmh_accept(FilterView v, PmmhDev p, int d, uint64_t move_seed, uint32_t c, double xi) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= v.ntheta) return;
+    if (m == 0) p.counts[0] = p.counts[1] = 0;   // the filters have run: ready for the next chain position
     bool acc = false;
     if (!p.skip[m]) {
         const double logZp = v.logZ[m], lpp = p.lp[2 * (size_t)m], lpc = p.lp[2 * (size_t)m + 1];

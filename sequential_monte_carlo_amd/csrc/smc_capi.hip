@@ -52,7 +52,10 @@ struct smc_filter_s {
     uint32_t brk_cap = 0, brk_count = 0;
     int64_t reccap = 0;
     unsigned char* d_skip = nullptr;           // smc_set_skip: filters log_likelihood leaves out
+    int32_t* d_order = nullptr;                //   and the order the one-workgroup-per-filter kernel takes them in: [ntheta] | n_active
     bool skip_on = false;
+    double* h_win = nullptr;                   // pinned [2][WIN_MAX][ntheta]: (logmu, ess) of the steps of a window
+    int win_k = 0;                             // steps of the pending window (smc_step_window), 0 = none
     // PMMH rejuvenation state (smc_pmmh_configure / smc_pmmh_rejuvenate): this handle holds the proposal filters
     PmmhSpec pm_spec{};
     bool pm_cfg = false;
@@ -159,6 +162,15 @@ static hipError_t do_resident(smc_filter_s* h, int T) {
     case MODEL_LG1D: return launch_resident<MODEL_LG1D>(h->v, T, h->d_recs, h->stream);
     case MODEL_SV1D: return launch_resident<MODEL_SV1D>(h->v, T, h->d_recs, h->stream);
     case MODEL_UCSV3D: return launch_resident<MODEL_UCSV3D>(h->v, T, h->d_recs, h->stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+static hipError_t do_window(smc_filter_s* h, int k, int bout) {
+    switch (h->model) {
+    case MODEL_LG1D: return launch_window<MODEL_LG1D>(h->v, k, h->d_recs, (int)h->t, h->cur, bout, h->h_win, h->stream);
+    case MODEL_SV1D: return launch_window<MODEL_SV1D>(h->v, k, h->d_recs, (int)h->t, h->cur, bout, h->h_win, h->stream);
+    case MODEL_UCSV3D: return launch_window<MODEL_UCSV3D>(h->v, k, h->d_recs, (int)h->t, h->cur, bout, h->h_win, h->stream);
     }
     return hipErrorInvalidValue;
 }
@@ -322,7 +334,9 @@ extern "C" int smc_destroy(smc_handle h) {
     }
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
-    (void)hipFree(h->d_skip);
+    (void)hipFree(h->d_skip); (void)hipFree(h->d_order);
+    if (h->h_win) (void)hipHostFree(h->h_win);
+    (void)hipFree(h->pm.order); (void)hipFree(h->pm.counts);
     (void)hipFree(h->pm.theta); (void)hipFree(h->pm.prop); (void)hipFree(h->pm.logZ); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip);
     (void)hipFree(h->pm.mask); (void)hipFree(h->pm.any); (void)hipFree(h->pm.nrun); (void)hipFree(h->pm.chol);
     if (h->d_brk) (void)hipFree(h->d_brk);
@@ -447,6 +461,7 @@ extern "C" int smc_init(smc_handle h, double y1, double* logmu) {
 extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
     if (!h) return fail(SMC_EINVAL, "smc_step: NULL handle");
     if (!h->inited) return fail(SMC_ESTATE, "smc_step: call smc_init (bootstrap_filter) first");
+    h->win_k = 0;   // an uncommitted window is dropped
     HIPCHK(hipSetDevice(h->device));
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -507,14 +522,70 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     if (resident && (rc = ensure_recs(h, T))) return rc;
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    h->v.skip = h->skip_on ? h->d_skip : nullptr;
+    if (h->skip_on) { h->v.skip = h->d_skip; h->v.order = h->d_order; h->v.n_active = h->d_order + h->v.ntheta; }
     rc = enqueue_log_likelihood(h, y[0], T, want_trace);
-    h->v.skip = nullptr;
+    h->v.skip = nullptr; h->v.order = nullptr; h->v.n_active = nullptr;
     if (rc) return rc;
     rc = finish_timing(h, logZ);
     if (rc) return rc;
     if (logmu_trace) HIPCHK(hipMemcpy(logmu_trace, h->d_tr_logmu, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
     if (ess_trace) HIPCHK(hipMemcpy(ess_trace, h->d_tr_ess, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
+
+// ---- k steps in one launch (the online sampler's window) ---------------------------------------------------------
+constexpr int WIN_MAX = 64;
+static int launch_window_steps(smc_handle h, int k) {
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(do_window(h, k, h->cur ^ 1));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    return SMC_OK;
+}
+extern "C" int smc_step_window(smc_handle h, const double* y, int k, double* logmu, double* ess) {
+    if (!h || !y) return fail(SMC_EINVAL, "smc_step_window: NULL argument");
+    if (!h->inited) return fail(SMC_ESTATE, "smc_step_window: call smc_init (bootstrap_filter) first");
+    if (k < 1 || k > WIN_MAX) return fail(SMC_EINVAL, "smc_step_window: 1 <= k <= 64");
+    if (h->v.nseg != 1 || !resident_supported(h->model, h->v.seg))
+        return fail(SMC_EINVAL, "smc_step_window: needs filters that fit the LDS-resident kernel (one segment); use smc_step");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = emit_if_needed(h);
+    if (rc) return rc;
+    if ((rc = ensure_y(h, WIN_MAX))) return rc;
+    if ((rc = ensure_recs(h, WIN_MAX))) return rc;
+    const size_t nt = (size_t)h->v.ntheta;
+    if (!h->h_win) HIPCHK(hipHostMalloc((void**)&h->h_win, 2 * (size_t)WIN_MAX * nt * 8, hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)k * 8, hipMemcpyHostToDevice, h->stream));
+    h->v.y = h->d_y;
+    rc = launch_window_steps(h, k);
+    h->v.y = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_ms = ms;
+    if (logmu) memcpy(logmu, h->h_win, (size_t)k * nt * 8);
+    if (ess) memcpy(ess, h->h_win + (size_t)k * nt, (size_t)k * nt * 8);
+    h->win_k = k;
+    return SMC_OK;
+}
+extern "C" int smc_step_commit(smc_handle h, int j) {
+    if (!h) return fail(SMC_EINVAL, "smc_step_commit: NULL handle");
+    if (h->win_k == 0) return fail(SMC_ESTATE, "smc_step_commit: no window pending (smc_step_window)");
+    if (j < 0 || j > h->win_k) return fail(SMC_EINVAL, "smc_step_commit: 0 <= j <= steps of the window");
+    HIPCHK(hipSetDevice(h->device));
+    const int k = h->win_k;
+    h->win_k = 0;
+    if (j == 0) return SMC_OK;            // nothing kept: the filters stand where they stood before the window
+    if (j < k) {                          // keep a prefix: the same j steps again (counter-based random numbers: the same bits)
+        h->v.y = h->d_y;
+        int rc = launch_window_steps(h, j);
+        h->v.y = nullptr;
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_commit, dim3((unsigned)((h->v.ntheta + 127) / 128)), dim3(128), 0, h->stream, h->v, j, h->d_recs);
+    HIPCHK(hipGetLastError());
+    h->cur ^= 1; h->t += (uint32_t)j; h->emitted = true;
+    HIPCHK(hipStreamSynchronize(h->stream));
     return SMC_OK;
 }
 
@@ -524,8 +595,18 @@ extern "C" int smc_set_skip(smc_handle h, const uint8_t* skip) {
     if (!h) return fail(SMC_EINVAL, "smc_set_skip: NULL handle");
     HIPCHK(hipSetDevice(h->device));
     if (!skip) { h->skip_on = false; return SMC_OK; }
-    if (!h->d_skip) HIPCHK(dalloc(&h->d_skip, (size_t)h->v.ntheta));
-    HIPCHK(hipMemcpyAsync(h->d_skip, skip, (size_t)h->v.ntheta, hipMemcpyHostToDevice, h->stream));
+    const int nt = h->v.ntheta;
+    if (!h->d_skip) HIPCHK(dalloc(&h->d_skip, (size_t)nt));
+    if (!h->d_order) HIPCHK(dalloc(&h->d_order, (size_t)nt + 1));
+    std::vector<int32_t> ord((size_t)nt + 1);
+    int na = 0, ns = 0;
+    for (int m = 0; m < nt; ++m) {
+        if (skip[m]) ord[(size_t)nt - 1 - ns++] = m;
+        else ord[(size_t)na++] = m;
+    }
+    ord[(size_t)nt] = na;
+    HIPCHK(hipMemcpyAsync(h->d_skip, skip, (size_t)nt, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_order, ord.data(), ord.size() * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->skip_on = true;
     return SMC_OK;
@@ -562,6 +643,8 @@ extern "C" int smc_pmmh_configure(smc_handle h, int d_theta, const int32_t* prio
         HIPCHK(dalloc(&h->pm.any, nt));
         HIPCHK(dalloc(&h->pm.nrun, 1));
         HIPCHK(dalloc(&h->pm.chol, MAX_DTHETA * MAX_DTHETA));
+        HIPCHK(dalloc(&h->pm.order, nt));
+        HIPCHK(dalloc(&h->pm.counts, 2));
         HIPCHK(hipHostMalloc((void**)&h->h_pm_out, (nt * (MAX_DTHETA + 2) + 1) * 8, hipHostMallocDefault));
     }
     h->pm_spec = sp;
@@ -613,6 +696,7 @@ extern "C" int smc_pmmh_rejuvenate(smc_handle h, smc_handle main, const double* 
     HIPCHK(hipMemcpyAsync(h->pm.chol, L8.data(), L8.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->pm.any, 0, (size_t)nt, h->stream));
     HIPCHK(hipMemsetAsync(h->pm.nrun, 0, 8, h->stream));
+    HIPCHK(hipMemsetAsync(h->pm.counts, 0, 8, h->stream));
     const dim3 grid((unsigned)((nt + 127) / 128)), block(128);
     for (int c = 0; c < chain; ++c) {
         hipLaunchKernelGGL(k_pmmh_propose, grid, block, 0, h->stream, h->v, sp, h->pm, h->model, move_seed, (uint32_t)c,
@@ -621,9 +705,9 @@ extern "C" int smc_pmmh_rejuvenate(smc_handle h, smc_handle main, const double* 
         h->have_params = true;
         h->v.seed = filter_seeds[c];
         h->brk_count = 0;                      // cached break points belong to the previous seed
-        h->v.skip = h->pm.skip;
+        h->v.skip = h->pm.skip; h->v.order = h->pm.order; h->v.n_active = h->pm.counts;
         rc = enqueue_log_likelihood(h, y[0], T, false);
-        h->v.skip = nullptr;
+        h->v.skip = nullptr; h->v.order = nullptr; h->v.n_active = nullptr;
         if (rc) return rc;
         hipLaunchKernelGGL(k_pmmh_accept, grid, block, 0, h->stream, h->v, h->pm, d, move_seed, (uint32_t)c, xi);
         HIPCHK(hipGetLastError());

@@ -17,5 +17,7 @@ bool geo_valid(int seg, int np, Geo& g);
 template <int MODEL> hipError_t launch_init(const FilterView& v, Geo g, int nxt, double y, hipStream_t s);
 template <int MODEL> hipError_t launch_step(const FilterView& v, Geo g, int cur, uint32_t t, int emit_prev, double y, hipStream_t s);
 template <int MODEL> hipError_t launch_resident(const FilterView& v, int T, StepRec* recs, hipStream_t s);
+// window mode: steps [t0, t0 + T) from the state in buffer bin to buffer bout, (logmu, ess) of every step to win
+template <int MODEL> hipError_t launch_window(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s);
 
 }  // namespace smc

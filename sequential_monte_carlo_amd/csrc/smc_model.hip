@@ -9,6 +9,20 @@
 
 namespace smc {
 
+// the attribute is per device: raise it wherever this process has not done so yet (cheap: a table lookup afterwards)
+template <class K>
+static hipError_t raise_lds_limit(K kernel, size_t lds, bool (&raised)[16]) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16 && raised[dev]) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev >= 0 && dev < 16) raised[dev] = true;
+    return e;
+}
+
+
 template <int THREADS, int NP>
 static hipError_t init_t(const FilterView& v, int nxt, double y, hipStream_t s) {
     const size_t lds = scr_words(THREADS, NP) * 8;
@@ -18,17 +32,11 @@ static hipError_t init_t(const FilterView& v, int nxt, double y, hipStream_t s) 
 template <int THREADS, int NP, bool SYS>
 static hipError_t step_sys_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
     const size_t lds = step_lds_bytes(v.nseg_p2, THREADS, NP, v.nseg > 1);
-    if (lds > 64 * 1024) {
-        static bool raised[2] = {false, false};   // per instantiation
-        const int m = v.nseg > 1 ? 1 : 0;
-        if (!raised[m]) {
-            hipError_t e = m ? hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, true, SYS>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                             : hipFuncSetAttribute((const void*)k_step<SMC_MODEL, THREADS, NP, false, SYS>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            raised[m] = true;
-        }
+    {
+        static bool raised[2][16] = {};   // per instantiation, variant and device
+        hipError_t e = v.nseg > 1 ? raise_lds_limit(k_step<SMC_MODEL, THREADS, NP, true, SYS>, lds, raised[1])
+                                  : raise_lds_limit(k_step<SMC_MODEL, THREADS, NP, false, SYS>, lds, raised[0]);
+        if (e != hipSuccess) return e;
     }
     if (v.nseg > 1)
         hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, true, SYS>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t,
@@ -71,29 +79,38 @@ hipError_t launch_step<SMC_MODEL>(const FilterView& v, Geo g, int cur, uint32_t 
     SMC_GEO_SWITCH(step_t, v, cur, t, emit_prev, y, s)
 }
 
-template <int THREADS, int NP, bool SYS>
-static hipError_t resident_sys_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
+template <int THREADS, int NP, bool SYS, bool WIN>
+static hipError_t resident_sys_t(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s) {
     const size_t lds = resident_lds_bytes<SMC_MODEL>(2 * NP * THREADS, THREADS, NP);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_resident<SMC_MODEL, THREADS, NP, SYS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((k_resident<SMC_MODEL, THREADS, NP, SYS>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs);
+    static bool raised[16] = {};   // per instantiation and device
+    hipError_t e = raise_lds_limit(k_resident<SMC_MODEL, THREADS, NP, SYS, WIN>, lds, raised);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_resident<SMC_MODEL, THREADS, NP, SYS, WIN>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs, t0, bin, bout, win);
     return hipGetLastError();
 }
 template <int THREADS, int NP>
 static hipError_t resident_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
-    return v.systematic ? resident_sys_t<THREADS, NP, true>(v, T, recs, s) : resident_sys_t<THREADS, NP, false>(v, T, recs, s);
+    return v.systematic ? resident_sys_t<THREADS, NP, true, false>(v, T, recs, 0, 0, 0, nullptr, s)
+                        : resident_sys_t<THREADS, NP, false, false>(v, T, recs, 0, 0, 0, nullptr, s);
+}
+template <int THREADS, int NP>
+static hipError_t window_t(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s) {
+    return v.systematic ? resident_sys_t<THREADS, NP, true, true>(v, T, recs, t0, bin, bout, win, s)
+                        : resident_sys_t<THREADS, NP, false, true>(v, T, recs, t0, bin, bout, win, s);
+}
+
+// threads / particle pairs per thread of the LDS-resident kernels for a segment length.  Measured (scripts/res_tune.py):
+// with few filters in flight (<= 4 waves per SIMD at two pairs per thread) the cheap LG model runs faster with one pair
+// per thread (twice the waves); SV / UCSV and large batches prefer two pairs per thread.  SMC_RES_NP (1, 2 or 4) overrides
+// the choice for tuning runs; results do not depend on it (tests/test_gpu_parity.py::test_launch_geometry_knobs).
+static int resident_np(const FilterView& v) {
+    const char* e = getenv("SMC_RES_NP");
+    return e ? atoi(e) : (SMC_MODEL == MODEL_LG1D && v.seg == 1024 && v.ntheta <= 1024) ? 1 : 0;
 }
 
 template <>
 hipError_t launch_resident<SMC_MODEL>(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
-    const char* e = getenv("SMC_RES_NP");   // tuning knob
-    // measured (scripts/res_tune.py): with few filters in flight (<= 4 waves per SIMD at two pairs per
-    // thread) the cheap LG model runs faster with one pair per thread (twice the waves); SV / UCSV and
-    // large batches prefer two pairs per thread
-    const int np = e ? atoi(e) : (SMC_MODEL == MODEL_LG1D && v.seg == 1024 && v.ntheta <= 1024) ? 1 : 0;
+    const int np = resident_np(v);
     switch (v.seg) {
     case 256: return resident_t<128, 1>(v, T, recs, s);
     case 512: return resident_t<256, 1>(v, T, recs, s);
@@ -102,6 +119,22 @@ hipError_t launch_resident<SMC_MODEL>(const FilterView& v, int T, StepRec* recs,
     case 4096: return np == 2 ? resident_t<1024, 2>(v, T, recs, s) : resident_t<512, 4>(v, T, recs, s);   // 1024 threads spill
     case 8192:
         if constexpr (model_dim<SMC_MODEL>::value == 1) return resident_t<1024, 4>(v, T, recs, s);
+        else return hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+
+template <>
+hipError_t launch_window<SMC_MODEL>(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s) {
+    const int np = resident_np(v);
+    switch (v.seg) {
+    case 256: return window_t<128, 1>(v, T, recs, t0, bin, bout, win, s);
+    case 512: return window_t<256, 1>(v, T, recs, t0, bin, bout, win, s);
+    case 1024: return np == 1 ? window_t<512, 1>(v, T, recs, t0, bin, bout, win, s) : window_t<256, 2>(v, T, recs, t0, bin, bout, win, s);
+    case 2048: return window_t<512, 2>(v, T, recs, t0, bin, bout, win, s);
+    case 4096: return window_t<512, 4>(v, T, recs, t0, bin, bout, win, s);
+    case 8192:
+        if constexpr (model_dim<SMC_MODEL>::value == 1) return window_t<1024, 4>(v, T, recs, t0, bin, bout, win, s);
         else return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;

@@ -15,8 +15,14 @@ __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int n
     return (size_t)lds_padded_len(seg) * 8 * (1 + model_dim<MODEL>::value) + scr_words(threads, np) * 8;
 }
 
-template <int MODEL, int THREADS, int NP, bool SYS = false>
-__global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepRec* recs /*[ntheta][T]*/) {
+// Window mode (WIN): the same loop over the steps [t0, t0 + T) of filters that already exist (t0 >= 1): the state is
+// read from buffer `bin`, the T steps run in LDS, the state after them goes to buffer `bout`, and (logmu_t, ess_t) of
+// every step go to `win` ([2][T][ntheta], pinned host memory) - nothing else of the handle changes (logZ and the
+// "last emitted" values are advanced by k_commit once the host has decided to keep the steps).  This is the
+// speculative multi-step call of the online sampler (smc_step_window): bootstrap_filter! k times in one launch.
+template <int MODEL, int THREADS, int NP, bool SYS = false, bool WIN = false>
+__global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepRec* recs /*[ntheta][T]*/, int t0, int bin, int bout,
+                                                      double* win) {
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -26,8 +32,18 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     uint64_t* scr = (uint64_t*)(smem + (size_t)SEGP * 8 + (size_t)SEGP * 8 * D);
     uint64_t* usys = scr + scr_words(THREADS, NP) - 8;   // SYS: the steps' uniforms (tail words nobody else uses)
     constexpr int NU = (THREADS / WAVE) < 8 ? (THREADS / WAVE) : 8;
-    const int th = blockIdx.x, tid = threadIdx.x;
-    if (v.skip && v.skip[th]) {   // a filter that is not run (proposal outside the prior's support): logZ = -inf
+    const int tid = threadIdx.x;
+    int th = blockIdx.x;
+    if (v.order) {   // active filters first (see FilterView::order); the others are not run: logZ = -inf
+        th = v.order[blockIdx.x];
+        if ((int)blockIdx.x >= *v.n_active) {
+            if (tid == 0) {
+                v.logZ[th] = -inf();
+                if (v.host_out) v.host_out[th] = -inf();
+            }
+            return;
+        }
+    } else if (v.skip && v.skip[th]) {   // a filter that is not run (proposal outside the prior's support): logZ = -inf
         if (tid == 0) {
             v.logZ[th] = -inf();
             if (v.host_out) v.host_out[th] = -inf();
@@ -43,9 +59,26 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
     double lw[NP][2];
     int anc[NQ];
     uint64_t S = 0;
+    if (WIN) {   // the filters' current state into LDS
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int i0 = 2 * (tid + k * THREADS);
+#pragma unroll
+            for (int c = 0; c < D; ++c)
+                *reinterpret_cast<double2*>(xs + c * SEGP + lds_pad(i0)) =
+                    *reinterpret_cast<const double2*>(v.x[bin] + ((size_t)c * v.ntheta + th) * v.npad + i0);
+            *reinterpret_cast<ulonglong2*>(Cs + lds_pad(i0)) = *reinterpret_cast<const ulonglong2*>(v.C[bin] + (size_t)th * v.npad + i0);
+        }
+        S = v.segS[bin][th];
+        if (SYS && tid < NU) {   // the uniforms of the first NU steps (afterwards refreshed inside the loop as usual)
+            const u32x4 uw = draw(v.seed, 0u, stream, (uint32_t)(t0 + tid), SLOT_SYS);
+            usys[(t0 - 1 + tid) % NU] = ((uint64_t)uw.v[1] << 32) | uw.v[0];
+        }
+        __syncthreads();
+    }
 
-    for (int t = 0; t < T; ++t) {
-        const double y = v.y[t];
+    for (int t = t0; t < t0 + T; ++t) {
+        const double y = v.y[t - t0];
         double xp[NQ][D];
         if (t > 0) {
             // a = resample(weights); xp = x[a]: the NQ searches of a thread advance level by level
@@ -122,12 +155,12 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
                 *reinterpret_cast<double2*>(xs + c * SEGP + lds_pad(i0)) = o;
             }
         }
-        const SegRec r = segment_normalize<THREADS, NP, true>(lw, scr, Cs, v.want_s2 != 0 || t == T - 1);
+        const SegRec r = segment_normalize<THREADS, NP, true>(lw, scr, Cs, WIN || v.want_s2 != 0 || t == t0 + T - 1);
         S = r.S;
         if (tid == 0) {
             StepRec o;
             o.kb = r.kb; o.S = r.S; o.hi = r.hi; o.lo = r.lo;
-            rec[t] = o;
+            rec[t - t0] = o;
         }
         if (SYS && (t % NU) == 0 && (tid & (WAVE - 1)) == 0 && tid / WAVE < NU) {
             // the uniforms of the next NU steps: wave w draws u(t+1+w) - every wave pays one Philox call per NU
@@ -139,15 +172,15 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         __syncthreads();  // Cs, xs complete; scr free
     }
 
-    // state out: same layout as the k_step path leaves in buffer 0
+    // state out: same layout as the k_step path leaves it (log_likelihood: buffer 0)
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int i0 = 2 * (tid + k * THREADS);
 #pragma unroll
         for (int c = 0; c < D; ++c)
-            *reinterpret_cast<double2*>(v.x[0] + ((size_t)c * v.ntheta + th) * v.npad + i0) =
+            *reinterpret_cast<double2*>(v.x[bout] + ((size_t)c * v.ntheta + th) * v.npad + i0) =
                 *reinterpret_cast<const double2*>(xs + c * SEGP + lds_pad(i0));
-        *reinterpret_cast<ulonglong2*>(v.C[0] + (size_t)th * v.npad + i0) = *reinterpret_cast<const ulonglong2*>(Cs + lds_pad(i0));
+        *reinterpret_cast<ulonglong2*>(v.C[bout] + (size_t)th * v.npad + i0) = *reinterpret_cast<const ulonglong2*>(Cs + lds_pad(i0));
         if (v.anc) {
             int2 o;
             o.x = lds_unpad(anc[2 * k]);   // anc holds padded positions
@@ -165,6 +198,17 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
         const uint64_t Qb = o.S, Rb = seg_R(o.hi, o.lo, 0, 0);
         double logmu, ess;
         combine_outputs(o.kb, Qb, Rb, 0, v.n, logmu, ess);
+        if (WIN) {
+            win[(size_t)t * v.ntheta + th] = logmu;
+            win[((size_t)T + t) * v.ntheta + th] = ess;
+            if (t == T - 1) {   // the record of the state in buffer bout
+                v.segk[bout][th] = o.kb;
+                v.segS[bout][th] = o.S;
+                v.segS2hi[bout][th] = o.hi;
+                v.segS2lo[bout][th] = o.lo;
+            }
+            continue;
+        }
         if (v.trace_logmu) v.trace_logmu[(size_t)t * v.ntheta + th] = logmu;
         if (v.trace_ess) v.trace_ess[(size_t)t * v.ntheta + th] = ess;
         if (stage_lds) lm[t] = logmu;
@@ -178,12 +222,13 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
             }
             v.last_K[th] = o.kb;
             v.last_D[th] = Qb;
-            v.segk[0][th] = o.kb;
-            v.segS[0][th] = o.S;
-            v.segS2hi[0][th] = o.hi;
-            v.segS2lo[0][th] = o.lo;
+            v.segk[bout][th] = o.kb;
+            v.segS[bout][th] = o.S;
+            v.segS2hi[bout][th] = o.hi;
+            v.segS2lo[bout][th] = o.lo;
         }
     }
+    if (WIN) return;
     __syncthreads();
     if (tid == 0) {
         double z = 0.0;

@@ -397,12 +397,72 @@ def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
         resample_(smc)
         rejuvenate_(smc, y[: t - 1], 1.0, verbose, out)
         _exchange(smc, y[: t - 1], verbose, out)
-    logw = np.log(smc.omega)
+    return _step_only(smc, y, t, verbose, out)
+
+
+def smc2_run(smc, y, t_from, t_to, window=8, verbose=True, out=sys.stdout):
+    """for t in t_from:t_to  smc²!(smc, y, t)  end   (the online loop of smc_samplers.jl:308-340 / README.md:93-101),
+    with the same results bit for bit, but up to `window` propagation steps per device call: between two
+    resample-move decisions the inner filters only need y[t], so a window of steps runs in ONE launch with the particle
+    clouds resident in LDS (smc_step_window), the host then walks through the window's outer ESS values exactly as
+    smc²! would, and keeps the steps up to (and including) the first one whose ESS falls below the threshold
+    (smc_step_commit; the speculated steps behind it are dropped and redone after the resample-move).
+    With sharded theta the window's log-likelihood increments are exchanged in one all-gather instead of one per step."""
+    y = np.asarray(y, dtype=np.float64)
+    t = int(t_from)
+    while t <= t_to:
+        k = min(int(window), t_to - t + 1)
+        if k <= 1 or not getattr(smc._main, "can_window", False):
+            smc2_step(smc, y, t, verbose, out)
+            t += 1
+            continue
+        if verbose:
+            out.write("t = %4d\tess = %4.3f" % (t - 1, smc.ess))
+        if smc.ess < smc.ess_min:
+            resample_(smc)
+            rejuvenate_(smc, y[: t - 1], 1.0, verbose, out)
+            _exchange(smc, y[: t - 1], verbose, out)
+            if not getattr(smc._main, "can_window", False):     # exchange! may have outgrown the resident kernel
+                _step_only(smc, y, t, verbose, out)
+                t += 1
+                continue
+        _sync_params(smc)
+        lik, _ = smc._main.step_window(y[t - 1: t - 1 + k])          # [k][M_local]
+        lik = np.asarray(lik, dtype=np.float64)
+        if smc.comm is not None:
+            per = smc.hi - smc.lo
+            lik = smc._gather(lik.ravel()).reshape(-1, k, per).transpose(1, 0, 2).reshape(k, smc.M)
+        j = 0
+        while j < k:
+            logw = np.log(smc.omega) + lik[j]
+            smc.logZ = smc.logZ + lik[j]
+            _, smc.omega, smc.ess = _reweight(logw)
+            j += 1
+            smc.t = t + j - 1
+            if verbose:
+                out.write("\n")
+            if smc.ess < smc.ess_min or j == k:
+                break
+            if verbose:
+                out.write("t = %4d\tess = %4.3f" % (t + j - 1, smc.ess))
+        smc._main.step_commit(j)
+        smc.psteps += smc.M * smc.N * j
+        t += j
+    return smc
+
+
+def _sync_params(smc):
+    """the parameter rows on the device follow theta (resample!/rejuvenate! change it); unchanged -> no upload"""
     th_loc = smc.theta[smc.lo:smc.hi]
     if smc._theta_dev is None or smc._theta_dev[0] is not smc._main or not np.array_equal(smc._theta_dev[1], th_loc):
-        # the parameter rows on the device follow theta (resample!/rejuvenate! change it); unchanged -> no upload
         smc._main.set_params(_rows(smc._models(th_loc))[1])
         smc._theta_dev = (smc._main, th_loc.copy())
+
+
+def _step_only(smc, y, t, verbose, out):
+    """the propagation half of smc²! (smc_samplers.jl:323-338), without the degeneracy check"""
+    logw = np.log(smc.omega)
+    _sync_params(smc)
     lik, _ = smc._main.step(float(y[t - 1]))
     lik = smc._gather(np.asarray(lik, dtype=np.float64))
     smc.psteps += smc.M * smc.N

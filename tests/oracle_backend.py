@@ -29,10 +29,32 @@ class OracleHandle:
     def log_likelihood(self, y):
         return np.array([f.log_likelihood(y) for f in self.f])
 
+    # the window of the online sampler (smc_step_window / smc_step_commit): k steps, then keep the first j
+    can_window = True
+
+    def _blank(self):
+        raw = [0.5, 1, 1, 1, 0, 1] if self.model_id == 1 else ([0, 0.5, 1] if self.model_id == 2 else [1, 1, 0, 0, 0])
+        return ob.Filter(self.model_id, raw, self.N, seg=self.seg)
+
+    def step_window(self, y):
+        self._snap = [self._blank() for _ in self.f]
+        for s, f in zip(self._snap, self.f):
+            s.copy_state_from(f)
+        self._win_y = np.array(y, dtype=np.float64)
+        r = [self.step(float(v)) for v in self._win_y]
+        return np.array([a for a, _ in r]), np.array([b for _, b in r])
+
+    def step_commit(self, j):
+        if j < len(self._win_y):
+            for s, f in zip(self._snap, self.f):
+                f.copy_state_from(s)
+            for v in self._win_y[:j]:
+                self.step(float(v))
+        self._snap = None
+
     def permute(self, a):
         # value copy: snapshot the sources first
-        snap = [ob.Filter(self.model_id, [0.5, 1, 1, 1, 0, 1] if self.model_id == 1 else ([0, 0.5, 1] if self.model_id == 2 else [1, 1, 0, 0, 0]),
-                          self.N, seg=self.seg) for _ in self.f]
+        snap = [self._blank() for _ in self.f]
         for s, f in zip(snap, self.f):
             s.copy_state_from(f)
         for m, f in enumerate(self.f):

@@ -65,14 +65,16 @@ def test_batched_models_and_ucsv_shapes(ob):
     assert a.min() >= 0 and a.max() <= 99 and abs(a.mean() - np.sum(np.arange(100) * ww)) < 2.0
 
 
-def _run(backend, online, device=False, min_ar=-1.0):
+def _run(backend, online, device=False, min_ar=-1.0, window=0):
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 24, seed=1998)
     s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, min_ar=min_ar, seed=7, backend=backend, theta_map=LG_TMAP if device else None)
     assert s.device_pmmh == device
     buf = io.StringIO()
     if online:
         smc.smc2(s, y)
-        for t in range(2, 25):
+        if window:
+            smc.smc2_run(s, y, 2, 24, window=window, verbose=True, out=buf)
+        for t in range(2, 25) if not window else ():
             smc.smc2_step(s, y, t, verbose=True, out=buf)
         x, w, _ = s._main.state()
         return s, buf.getvalue(), x, w
@@ -165,6 +167,20 @@ def test_smc2_online_hip_equals_oracle_backend(device):
     assert th == to and "[rejuvenating]" in th
     assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
     assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo)) and sh.psteps == so.psteps
+
+
+def test_windowed_smc2_run_on_gpu():
+    """smc2_run over smc_step_window / smc_step_commit == the step-by-step loop == the oracle backend, whole runs;
+    also with exchange! doubling the particle count in the middle (the window then follows the new handle)."""
+    ref, tref, xr, wr = _run(OracleBackend(), online=True, device=True)
+    for window in (4, 8, 64):
+        sh, th, xh, wh = _run(smc.smc_samplers.HipBackend(), online=True, device=True, window=window)
+        assert th == tref and sh.psteps == ref.psteps
+        assert np.array_equal(bits(sh.theta), bits(ref.theta)) and np.array_equal(bits(sh.logZ), bits(ref.logZ))
+        assert np.array_equal(bits(sh.omega), bits(ref.omega)) and np.array_equal(bits(xh), bits(xr)) and np.array_equal(bits(wh), bits(wr))
+    ref, tref, xr, wr = _run(OracleBackend(), online=True, device=False, min_ar=2.0)
+    sh, th, xh, wh = _run(smc.smc_samplers.HipBackend(), online=True, device=False, min_ar=2.0, window=6)
+    assert th == tref and "particles added" in th and np.array_equal(bits(sh.logZ), bits(ref.logZ)) and np.array_equal(bits(xh), bits(xr))
 
 
 @pytest.mark.parametrize("device", [False, True])

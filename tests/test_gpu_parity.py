@@ -638,3 +638,76 @@ def test_randomized_configurations(L, ob):
             assert same(lm[:, th], olm) and same(es[:, th], oes), ctx
             assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa), ctx
         h.close()
+
+
+def test_step_window_equals_single_steps(L, ob):
+    """smc_step_window (k bootstrap_filter! steps in one LDS-resident launch, nothing kept) + smc_step_commit(j):
+    (logmu, ess) of every step and the state after the kept prefix are those of j smc_step calls / of the oracle,
+    for every model, one or two particle pairs per thread, multinomial and systematic resampling."""
+    for model, n, seg, fl in ((1, 1024, 0, 0), (1, 1000, 0, 0), (2, 2048, 0, 0), (3, 1024, 0, 0), (3, 300, 512, 0),
+                              (1, 1024, 0, L.FLAG_SYSTEMATIC), (3, 777, 0, L.FLAG_SYSTEMATIC), (1, 8192, 0, 0)):
+        raw, nth, T = RAW[model], 3, 26
+        _, y = ob.simulate(model, raw, T, 11)
+        h = L.Handle(model, nth, n, seg=seg, seed=41, flags=fl | L.FLAG_ANCESTORS)
+        assert h.can_window
+        h.set_params(np.tile(raw, (nth, 1)))
+        fs = [ob.Filter(model, raw, n, seg=seg, seed=41, stream=th, systematic=bool(fl & L.FLAG_SYSTEMATIC)) for th in range(nth)]
+        acc = h.init(y[0]).copy()
+        assert same(acc, [f.bootstrap_filter(y[0]) for f in fs])
+        t = 1
+        for k, j in ((5, 5), (8, 3), (4, 0), (1, 1), (9, 9), (6, 1)):
+            x0, w0, _ = h.state(want_anc=False)
+            lm, es = h.step_window(y[t:t + k])
+            x1, w1, _ = h.state(want_anc=False)
+            assert same(x1, x0) and same(w1, w0)                   # a window does not move the filters ...
+            h.step_commit(j)                                       # ... until a prefix of it is kept
+            for i in range(j):
+                ref = [f.step(y[t + i]) for f in fs]
+                assert same(lm[i], [r[0] for r in ref]) and same(es[i], [r[1] for r in ref]), (model, n, k, j, i)
+                acc += lm[i]
+            t += j
+            x, w, a = h.state()
+            for th in range(nth):
+                ox, ow, oa, _ = fs[th].state()
+                assert same(x[:, th], ox) and same(w[th], ow), (model, n, k, j, th)
+                if j:
+                    assert np.array_equal(a[th], oa)
+            assert same(h.logZ()[0], acc)
+        lm1, es1 = h.step(y[t])                                    # and the single-step API goes on from there
+        ref = [f.step(y[t]) for f in fs]
+        assert same(lm1, [r[0] for r in ref]) and same(es1, [r[1] for r in ref])
+        h.close()
+    h = L.Handle(1, 1, 5000, seg=1024, seed=1)
+    h.set_params(LG)
+    h.init(0.1)
+    assert not h.can_window
+    with pytest.raises(L.SmcError):
+        h.step_window([0.1, 0.2])
+    h.close()
+
+
+def test_launch_geometry_knobs_do_not_change_results(L, ob):
+    """SMC_NP (particle pairs per thread of k_init/k_step, read by smc_create) and SMC_RES_NP (of the LDS-resident
+    kernels, read at launch) are tuning knobs: any admissible value gives the oracle's bits."""
+    import os
+    _, y = ob.simulate(1, LG, 12, 1998)
+    try:
+        for knob, vals, cfgs in (("SMC_NP", ("1", "2", "4"), ((5000, 1024, L.FLAG_NO_RESIDENT), (1024, 0, L.FLAG_NO_RESIDENT), (40000, 2048, 0))),
+                                 ("SMC_RES_NP", ("1", "2", "4"), ((1024, 0, 0), (2048, 0, 0), (700, 1024, 0)))):
+            for n, seg, fl in cfgs:
+                f = ob.Filter(1, LG, n, seg=seg, seed=3)
+                z, olm, oes = f.log_likelihood(y, trace=True)
+                ox, ow, oa, _ = f.state()
+                for v in vals:
+                    os.environ[knob] = v
+                    h = L.Handle(1, 1, n, seg=seg, seed=3, flags=fl | L.FLAG_ANCESTORS)
+                    h.set_params(LG)
+                    logZ, lm, es = h.log_likelihood(y, trace=True)
+                    x, w, a = h.state()
+                    assert bits([logZ[0]])[0] == bits([z])[0] and same(lm[:, 0], olm) and same(es[:, 0], oes), (knob, v, n, seg)
+                    assert same(x[:, 0], ox) and same(w[0], ow) and np.array_equal(a[0], oa), (knob, v, n, seg)
+                    h.close()
+            os.environ.pop(knob, None)
+    finally:
+        os.environ.pop("SMC_NP", None)
+        os.environ.pop("SMC_RES_NP", None)

@@ -195,18 +195,39 @@ def test_smc2_online_runs_and_tracks():
     assert -1 < th[0] < 1 and th[1] > 0 and th[2] > 0
 
 
-def run_online(M=24, N=64, T=30, seed=5, comm=None, device=False):
+def run_online(M=24, N=64, T=30, seed=5, comm=None, device=False, window=0, text=None):
+    """window = 0: the reference's loop, one smc²! per observation; > 0: smc2_run with that many steps per call"""
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
     s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm,
                 theta_map=LG_TMAP if device else None)
     smc.smc2(s, y)
     moves = 0
-    for t in range(2, T + 1):
+    if window:
         before = s._calls
-        smc.smc2_step(s, y, t, verbose=False)
-        moves += s._calls > before
+        smc.smc2_run(s, y, 2, T, window=window, verbose=text is not None, out=text)
+        moves = s._calls - before
+    else:
+        for t in range(2, T + 1):
+            before = s._calls
+            smc.smc2_step(s, y, t, verbose=text is not None, out=text)
+            moves += s._calls > before
     x, w, _ = s._main.state()
     return s, moves, x, w
+
+
+def test_windowed_online_run_equals_step_loop():
+    """smc2_run (several propagation steps per device call, speculated and rolled back around resample-moves) gives
+    the same sampler as the reference's `for t in 2:T smc²!(smc,y,t)` loop: bits, log text, counted particle-steps."""
+    for device in (False, True):
+        ta = io.StringIO()
+        a, moves, xa, wa = run_online(device=device, text=ta)
+        assert moves >= 1
+        for window in (1, 3, 8, 64):
+            tb = io.StringIO()
+            b, _, xb, wb = run_online(device=device, window=window, text=tb)
+            assert ta.getvalue() == tb.getvalue(), (device, window)
+            assert np.array_equal(a.theta, b.theta) and np.array_equal(a.logZ, b.logZ) and np.array_equal(a.omega, b.omega)
+            assert np.array_equal(xa, xb) and np.array_equal(wa, wb) and a.psteps == b.psteps and a.t == b.t
 
 
 WORKER = r'''
@@ -223,7 +244,7 @@ for device in (False, True):      # host-loop rejuvenation / one-call-per-rank r
     assert (s.lo, s.hi) == ((0, 16) if dist.get_rank() == 0 else (16, 32))
     np.save(tag + ".%d.npy" % dist.get_rank(), np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]]))
     # online SMC^2 with theta sharded: resample! moves whole filters between the two ranks (all-to-all)
-    so, moves, x, w = run_online(comm=ThetaComm(dist), device=device)
+    so, moves, x, w = run_online(comm=ThetaComm(dist), device=device, window=5 if device else 0)
     assert moves >= 1
     np.save(tag + ".online.%d.npy" % dist.get_rank(), np.concatenate([so.theta.ravel(), so.logZ, so.omega, x.ravel(), w.ravel()]))
 dist.destroy_process_group()
