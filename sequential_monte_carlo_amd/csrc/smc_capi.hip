@@ -521,8 +521,8 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
     if (resident && (rc = ensure_recs(h, T))) return rc;
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (h->skip_on) { h->v.skip = h->d_skip; h->v.order = h->d_order; h->v.n_active = h->d_order + h->v.ntheta; }
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
     rc = enqueue_log_likelihood(h, y[0], T, want_trace);
     h->v.skip = nullptr; h->v.order = nullptr; h->v.n_active = nullptr;
     if (rc) return rc;

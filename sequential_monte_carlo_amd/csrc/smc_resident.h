@@ -101,14 +101,14 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
             }
             // the search carries the padded position as an LDS byte pointer (one ds_read_b64 with an
             // immediate offset per probe); xs is padded like Cs, so the gather uses it as it stands
-            const char* pb[NQ];
+            lds_byte* pb[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) pb[i] = (const char*)Cs;
+            for (int i = 0; i < NQ; ++i) pb[i] = lds_ptr(Cs);
 #pragma unroll
             for (int s = SEG >> 1; s >= 1; s >>= 1) {
                 uint64_t val[NQ];
 #pragma unroll
-                for (int i = 0; i < NQ; ++i) val[i] = *reinterpret_cast<const uint64_t*>(pb[i] + 8 * lds_probe_off(s));
+                for (int i = 0; i < NQ; ++i) val[i] = lds_load_u64(pb[i] + 8 * lds_probe_off(s));
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) pb[i] += (val[i] <= T2[i]) ? 8 * lds_step_inc(s) : 0;
             }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepR
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const int own = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
-                int ap = S ? (int)(pb[i] - (const char*)Cs) >> 3 : lds_pad(own);   // collapsed filter: identity
+                int ap = S ? (int)(pb[i] - lds_ptr(Cs)) >> 3 : lds_pad(own);   // collapsed filter: identity
                 ap = ap < last_p ? ap : last_p;   // lds_pad is increasing: the clamp to n-1 commutes with it
                 anc[i] = ap;
 #pragma unroll

@@ -72,6 +72,15 @@ SMC_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 #endif
 }
 
+// a ^ b ^ c: one v_bitop3_b32 on gfx950 (the compiler does not form it by itself)
+SMC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 SMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -79,7 +88,7 @@ SMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
         const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
-        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        const uint32_t n0 = xor3(h1, c1, k0), n2 = xor3(h0, c3, k1);
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -91,6 +100,26 @@ SMC_HD u32x4 draw(uint64_t seed, uint32_t pair, uint32_t stream, uint32_t t, uin
     return philox4x32_10(pair, stream, t, slot, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// fma(p, r, c) with a compile-time constant c.  On the device the constant sits in a scalar register pair filled by two
+// s_mov_b32 (scalar issue port) and the instruction is the three-source v_fma_f64: the compiler's own choice, v_fmac_f64,
+// accumulates INTO the constant and so first copies every coefficient into vector registers - two v_mov_b32 per
+// coefficient, 29 % of Box-Muller's vector instructions.  Same IEEE fused multiply-add, same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <uint64_t BITS>
+__device__ __forceinline__ double fma_const(double p, double r) {
+    uint32_t lo, hi;
+    double d;
+    asm("s_mov_b32 %0, %1" : "=s"(lo) : "n"((uint32_t)BITS));
+    asm("s_mov_b32 %0, %1" : "=s"(hi) : "n"((uint32_t)(BITS >> 32)));
+    const double c = __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
+    return d;
+}
+#define SMC_FMAK(p, r, c) fma_const<__builtin_bit_cast(uint64_t, (double)(c))>((p), (r))
+#else
+#define SMC_FMAK(p, r, c) fma((p), (r), (c))
+#endif
+
 // ---- exp / log / sincos ----------------------------------------------------------------
 // exp(x) = p * 2^k, k = rint(x / ln2) returned as an integral double, p in [0.707, 1.415]; |x| <= 7e8
 SMC_HD double sp_exp_parts(double x, double& kout) {
@@ -98,19 +127,19 @@ SMC_HD double sp_exp_parts(double x, double& kout) {
     double r = fma(-k, LN2_HI, x);
     r = fma(-k, LN2_LO, r);
     double p = 0x1.6124613a86d09p-33;
-    p = fma(p, r, 0x1.1eed8eff8d898p-29);
-    p = fma(p, r, 0x1.ae64567f544e4p-26);
-    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = fma(p, r, 0x1.71de3a556c734p-19);
-    p = fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = fma(p, r, 0x1.6c16c16c16c17p-10);
-    p = fma(p, r, 0x1.1111111111111p-7);
-    p = fma(p, r, 0x1.5555555555555p-5);
-    p = fma(p, r, 0x1.5555555555555p-3);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    p = SMC_FMAK(p, r, 0x1.1eed8eff8d898p-29);
+    p = SMC_FMAK(p, r, 0x1.ae64567f544e4p-26);
+    p = SMC_FMAK(p, r, 0x1.27e4fb7789f5cp-22);
+    p = SMC_FMAK(p, r, 0x1.71de3a556c734p-19);
+    p = SMC_FMAK(p, r, 0x1.a01a01a01a01ap-16);
+    p = SMC_FMAK(p, r, 0x1.a01a01a01a01ap-13);
+    p = SMC_FMAK(p, r, 0x1.6c16c16c16c17p-10);
+    p = SMC_FMAK(p, r, 0x1.1111111111111p-7);
+    p = SMC_FMAK(p, r, 0x1.5555555555555p-5);
+    p = SMC_FMAK(p, r, 0x1.5555555555555p-3);
+    p = SMC_FMAK(p, r, 0.5);
+    p = SMC_FMAK(p, r, 1.0);
+    p = SMC_FMAK(p, r, 1.0);
     kout = k;
     return p;
 }
@@ -153,16 +182,16 @@ SMC_HD double sp_log(double x) {
     const double s = f / (2.0 + f);
     const double z = s * s;
     double R = 0x1.642c8590b2164p-4;
-    R = fma(R, z, 0x1.8618618618618p-4);
-    R = fma(R, z, 0x1.af286bca1af28p-4);
-    R = fma(R, z, 0x1.e1e1e1e1e1e1ep-4);
-    R = fma(R, z, 0x1.1111111111111p-3);
-    R = fma(R, z, 0x1.3b13b13b13b14p-3);
-    R = fma(R, z, 0x1.745d1745d1746p-3);
-    R = fma(R, z, 0x1.c71c71c71c71cp-3);
-    R = fma(R, z, 0x1.2492492492492p-2);
-    R = fma(R, z, 0x1.999999999999ap-2);
-    R = fma(R, z, 0x1.5555555555555p-1);
+    R = SMC_FMAK(R, z, 0x1.8618618618618p-4);
+    R = SMC_FMAK(R, z, 0x1.af286bca1af28p-4);
+    R = SMC_FMAK(R, z, 0x1.e1e1e1e1e1e1ep-4);
+    R = SMC_FMAK(R, z, 0x1.1111111111111p-3);
+    R = SMC_FMAK(R, z, 0x1.3b13b13b13b14p-3);
+    R = SMC_FMAK(R, z, 0x1.745d1745d1746p-3);
+    R = SMC_FMAK(R, z, 0x1.c71c71c71c71cp-3);
+    R = SMC_FMAK(R, z, 0x1.2492492492492p-2);
+    R = SMC_FMAK(R, z, 0x1.999999999999ap-2);
+    R = SMC_FMAK(R, z, 0x1.5555555555555p-1);
     R = R * z;
     const double dk = (double)e;
     return dk * LN2_HI - ((s * (f - R) - dk * LN2_LO) - f);
@@ -177,24 +206,24 @@ SMC_HD void sp_sincos2pi(double u, double& c, double& s) {
     const double y = g * PIO4;
     const double z = y * y;
     double ps = 0x1.952c77030ad4ap-49;
-    ps = fma(ps, z, -0x1.ae7f3e733b81fp-41);
-    ps = fma(ps, z, 0x1.6124613a86d09p-33);
-    ps = fma(ps, z, -0x1.ae64567f544e4p-26);
-    ps = fma(ps, z, 0x1.71de3a556c734p-19);
-    ps = fma(ps, z, -0x1.a01a01a01a01ap-13);
-    ps = fma(ps, z, 0x1.1111111111111p-7);
-    ps = fma(ps, z, -0x1.5555555555555p-3);
+    ps = SMC_FMAK(ps, z, -0x1.ae7f3e733b81fp-41);
+    ps = SMC_FMAK(ps, z, 0x1.6124613a86d09p-33);
+    ps = SMC_FMAK(ps, z, -0x1.ae64567f544e4p-26);
+    ps = SMC_FMAK(ps, z, 0x1.71de3a556c734p-19);
+    ps = SMC_FMAK(ps, z, -0x1.a01a01a01a01ap-13);
+    ps = SMC_FMAK(ps, z, 0x1.1111111111111p-7);
+    ps = SMC_FMAK(ps, z, -0x1.5555555555555p-3);
     const double sy = fma(y * z, ps, y);
     double pc = -0x1.6827863b97d97p-53;
-    pc = fma(pc, z, 0x1.ae7f3e733b81fp-45);
-    pc = fma(pc, z, -0x1.93974a8c07c9dp-37);
-    pc = fma(pc, z, 0x1.1eed8eff8d898p-29);
-    pc = fma(pc, z, -0x1.27e4fb7789f5cp-22);
-    pc = fma(pc, z, 0x1.a01a01a01a01ap-16);
-    pc = fma(pc, z, -0x1.6c16c16c16c17p-10);
-    pc = fma(pc, z, 0x1.5555555555555p-5);
-    pc = fma(pc, z, -0.5);
-    const double cy = fma(z, pc, 1.0);
+    pc = SMC_FMAK(pc, z, 0x1.ae7f3e733b81fp-45);
+    pc = SMC_FMAK(pc, z, -0x1.93974a8c07c9dp-37);
+    pc = SMC_FMAK(pc, z, 0x1.1eed8eff8d898p-29);
+    pc = SMC_FMAK(pc, z, -0x1.27e4fb7789f5cp-22);
+    pc = SMC_FMAK(pc, z, 0x1.a01a01a01a01ap-16);
+    pc = SMC_FMAK(pc, z, -0x1.6c16c16c16c17p-10);
+    pc = SMC_FMAK(pc, z, 0x1.5555555555555p-5);
+    pc = SMC_FMAK(pc, z, -0.5);
+    const double cy = SMC_FMAK(z, pc, 1.0);
     const bool swap = ((oct + 1) & 2) != 0;
     double cc = swap ? sy : cy;
     double ss = swap ? cy : sy;
