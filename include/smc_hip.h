@@ -138,6 +138,28 @@ int smc_slot_bytes(smc_handle h, int64_t* bytes);
 int smc_pack_slots(smc_handle h, const int32_t* idx, int64_t k, void* device_buf);
 int smc_unpack_slots(smc_handle h, const int32_t* idx, int64_t k, const void* device_buf);
 
+/* ---- theta sharded over the GPUs of one node, for hosts without torch.distributed ---------------------
+ * One process per GPU.  Rank 0 calls smc_comm_unique_id and hands the SMC_COMM_ID_BYTES bytes to the other ranks by
+ * whatever means the host has (a file, a socket, Julia's Distributed); every rank then calls smc_comm_create.  RCCL
+ * (xGMI) underneath, opened with dlopen at the first call.  The collectives are the ones the samplers have:
+ *   smc_outer_reweight       reweight(logZ) / reweight(logw) of src/smc_samplers.jl:232,249,265,298,338 with the
+ *                            entries sharded over the ranks: one all-gather of the slices, then normalize() on every rank
+ *                            (w_all, logmu, ess identical everywhere; logw_all [n_local*world] may be NULL)
+ *   smc_comm_all_gather      n doubles per rank -> [world][n] on every rank (theta / logZ / accepted after rejuvenate!)
+ *   smc_comm_exchange_slots  resample!(smc) of the online sampler (src/smc_samplers.jl:74-84) when the filters of `h`
+ *                            are sharded: a[m] is the GLOBAL ancestor of GLOBAL slot m (same vector on every rank, rank r
+ *                            holds slots [r M/world, (r+1) M/world)); whole filters travel device to device */
+#define SMC_COMM_ID_BYTES 128
+typedef struct smc_comm_s* smc_comm;
+int smc_comm_unique_id(void* id /*[SMC_COMM_ID_BYTES] out*/);
+int smc_comm_create(const void* id, int rank, int world, int device, smc_comm* out);
+int smc_comm_destroy(smc_comm c);
+int smc_comm_rank(smc_comm c, int* rank, int* world);
+int smc_comm_all_gather(smc_comm c, const double* local /*[n]*/, int64_t n, double* all /*[world][n]*/);
+int smc_outer_reweight(smc_comm c, const double* logw_local /*[n_local]*/, int64_t n_local, double* logw_all,
+                       double* w_all /*[n_local*world]*/, double* logmu, double* ess);
+int smc_comm_exchange_slots(smc_comm c, smc_handle h, const int32_t* a /*[M]*/, int64_t M);
+
 /* raw fixed-point weight state (tests): C [n_theta][nseg*seg], m/S/S2hi/S2lo [n_theta][nseg] */
 int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo);
 int smc_get_geometry(smc_handle h, int* seg, int* nseg, int* d, int* resident);

@@ -23,7 +23,10 @@ EXPORTS = [
     "smc_host_box_muller", "smc_sys_targets", "smc_device_math", "smc_last_error", "smc_version",
     "smc_set_skip", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_host_pmmh_propose", "smc_host_pmmh_log_uniform",
     "smc_host_prior_logpdf", "smc_step_window", "smc_step_commit",
+    "smc_comm_unique_id", "smc_comm_create", "smc_comm_destroy", "smc_comm_rank", "smc_comm_all_gather", "smc_outer_reweight",
+    "smc_comm_exchange_slots",
 ]
+COMM_ID_BYTES = 128
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
 
 _dp = C.POINTER(C.c_double)
@@ -122,6 +125,13 @@ def lib():
     L.smc_host_pmmh_log_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
     L.smc_host_prior_logpdf.restype = C.c_double
     L.smc_host_prior_logpdf.argtypes = [C.c_int, _dp, C.c_double]
+    L.smc_comm_unique_id.argtypes = [C.c_void_p]
+    L.smc_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(h)]
+    L.smc_comm_destroy.argtypes = [h]
+    L.smc_comm_rank.argtypes = [h, _ip, _ip]
+    L.smc_comm_all_gather.argtypes = [h, _dp, C.c_int64, _dp]
+    L.smc_outer_reweight.argtypes = [h, _dp, C.c_int64, _dp, _dp, _dp, _dp]
+    L.smc_comm_exchange_slots.argtypes = [h, h, _i32p, C.c_int64]
     L.smc_last_error.restype = C.c_char_p
     L.smc_version.restype = C.c_char_p
     _lib = L
@@ -189,6 +199,52 @@ def device_math(which, a, b=None, device=0):
     out = np.zeros_like(a)
     check(lib().smc_device_math(which, _d(a), _d(b), a.size, _d(out), device))
     return out
+
+
+def comm_unique_id():
+    """the bytes rank 0 hands to the other ranks (smc_comm_unique_id)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib().smc_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """The samplers' collectives inside libsmchip.so over RCCL (smc_comm_*): what a host without torch.distributed
+    binds to shard theta over the GPUs of a node.  Same interface as distributed.ThetaComm."""
+
+    def __init__(self, unique_id, rank, world, device=0):
+        self._c = C.c_void_p()
+        self.rank, self.world = int(rank), int(world)
+        check(lib().smc_comm_create(C.c_char_p(bytes(unique_id)), self.rank, self.world, int(device), C.byref(self._c)))
+
+    def close(self):
+        if getattr(self, "_c", None):
+            lib().smc_comm_destroy(self._c)
+            self._c = None
+
+    def slice(self, M):
+        if M % self.world:
+            raise ValueError("n_theta (%d) must be a multiple of the number of ranks (%d)" % (M, self.world))
+        per = M // self.world
+        return self.rank * per, (self.rank + 1) * per
+
+    def all_gather(self, local):
+        local = np.ascontiguousarray(local, dtype=np.float64).ravel()
+        out = np.zeros(local.size * self.world)
+        check(lib().smc_comm_all_gather(self._c, _d(local), local.size, _d(out)))
+        return out
+
+    def outer_reweight(self, logw_local):
+        """(logmu, w [n_local*world], ess, logw_all) of the sharded log-weights: reweight on every rank"""
+        lw = np.ascontiguousarray(logw_local, dtype=np.float64).ravel()
+        allw, w = np.zeros(lw.size * self.world), np.zeros(lw.size * self.world)
+        lm, ess = C.c_double(), C.c_double()
+        check(lib().smc_outer_reweight(self._c, _d(lw), lw.size, _d(allw), _d(w), C.byref(lm), C.byref(ess)))
+        return lm.value, w, ess.value, allw
+
+    def exchange_slots(self, h, a, M):
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        check(lib().smc_comm_exchange_slots(self._c, h._h, a.ctypes.data_as(_i32p), int(M)))
 
 
 class Handle:

@@ -23,6 +23,7 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+extern "C" int smc_set_error_(int code, const char* msg) { return fail(code, msg ? msg : ""); }   // for smc_comm.hip
 #define HIPCHK(expr)                                                                                          \
     do {                                                                                                      \
         hipError_t _e = (expr);                                                                               \

@@ -352,3 +352,50 @@ def test_sharded_online_smc2_single_rank_rccl():
         assert np.array_equal(bits(x0), bits(x1)) and np.array_equal(bits(w0), bits(w1))
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_comm_single_rank(ob):
+    """smc_comm_* (the samplers' collectives inside libsmchip.so over RCCL, for hosts without torch.distributed) with a
+    world of one rank: outer reweight == normalize, all-gather == identity, exchange_slots == smc_permute, and the whole
+    online sampler through it equals the unsharded run.  (More ranks need more GPUs than the test box has: the rank
+    arithmetic is the one distributed.ThetaComm runs in the world_size-2 gloo test.)"""
+    from sequential_monte_carlo_amd import _lib as L
+    c = L.Comm(L.comm_unique_id(), 0, 1, device=0)
+    try:
+        rng = np.random.default_rng(3)
+        logw = rng.normal(size=512) * 3 - 700
+        lm, w, ess, allw = c.outer_reweight(logw)
+        lm0, w0, ess0 = L.normalize(logw)
+        assert np.array_equal(bits(allw), bits(logw)) and np.array_equal(bits(w), bits(w0)) and (lm, ess) == (lm0, ess0)
+        v = rng.normal(size=77)
+        assert np.array_equal(bits(c.all_gather(v)), bits(v))
+        m = smc.UnivariateLinearGaussian(**LG)
+        _, y = smc.simulate(m, 8)
+        hs = []
+        for _ in range(2):
+            h = L.Handle(1, 6, 3000, seg=1024, seed=4)
+            h.set_params(np.tile(m.raw(), (6, 1)))
+            h.log_likelihood(y)
+            hs.append(h)
+        a = np.array([3, 3, 0, 5, 1, 1], dtype=np.int32)
+        hs[0].permute(a)
+        c.exchange_slots(hs[1], a, 6)
+        for q0, q1 in zip(hs[0].state(want_anc=False)[:2] + hs[0].logZ(), hs[1].state(want_anc=False)[:2] + hs[1].logZ()):
+            assert np.array_equal(bits(q0), bits(q1))
+        for h in hs:
+            h.close()
+        _, y = smc.simulate(m, 24, seed=1998)
+
+        def run(comm):
+            s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, seed=7, backend=smc.smc_samplers.HipBackend(), comm=comm, theta_map=LG_TMAP)
+            smc.smc2(s, y)
+            smc.smc2_run(s, y, 2, 24, window=5, verbose=False)
+            x, w_, _ = s._main.state()
+            return s, x, w_
+
+        s0, x0, w0_ = run(None)
+        s1, x1, w1_ = run(c)
+        assert np.array_equal(bits(s0.theta), bits(s1.theta)) and np.array_equal(bits(s0.logZ), bits(s1.logZ))
+        assert np.array_equal(bits(x0), bits(x1)) and np.array_equal(bits(w0_), bits(w1_))
+    finally:
+        c.close()

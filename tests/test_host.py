@@ -132,3 +132,64 @@ def test_bench_launcher_starts_the_ranks_itself():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "nope"],
                          capture_output=True, text=True, timeout=120, env=env)
     assert bad.returncode != 0
+
+
+def _header_signatures():
+    """{name: (return type, [argument types])} of every function include/smc_hip.h declares, const and names dropped"""
+    hdr = open(os.path.join(ROOT, "include", "smc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    sigs = {}
+    for ret, name, args in re.findall(r"\b(int|double|void|const char\s*\*)\s+(smc_\w+)\s*\(([^;{}]*?)\)\s*;", hdr, flags=re.S):
+        types = []
+        for a in args.split(","):
+            a = re.sub(r"\bconst\b", " ", a).strip()
+            if a in ("void", ""):
+                continue
+            m = re.match(r"(.*?)(\b\w+\b)?\s*(\[\d*\])?\s*$", a)          # type, [parameter name], [array suffix]
+            ty = a if "*" in a and a.rstrip().endswith("*") else m.group(1)
+            ty = re.sub(r"\s+", "", ty) + ("*" if m.group(3) else "")
+            types.append(ty)
+        sigs[name] = (re.sub(r"\s+|const", "", ret), types)
+    return sigs
+
+
+JULIA_TO_C = {
+    "Cint": {"int"}, "Int64": {"int64_t"}, "UInt64": {"uint64_t"}, "UInt32": {"uint32_t"}, "Float64": {"double"},
+    "Cstring": {"char*"}, "Ptr{Cvoid}": {"smc_handle", "smc_comm", "void*"}, "Ref{Ptr{Cvoid}}": {"smc_handle*", "smc_comm*"},
+    "Ptr{Float64}": {"double*"}, "Ptr{Int32}": {"int32_t*"}, "Ptr{UInt8}": {"uint8_t*"}, "Ptr{UInt64}": {"uint64_t*"},
+    "Ptr{Int64}": {"int64_t*"}, "Ptr{UInt32}": {"uint32_t*"},
+}
+
+
+def test_julia_binding_matches_header():
+    """Julia cannot run in this image, so every `ccall((:name, LIBSMC), Ret, (ArgTypes...), ...)` of julia/hip_backend.jl
+    is checked textually against include/smc_hip.h: the symbol exists, the return type, the arity and every argument
+    type agree; and types are defined before the first method that names them (the include-order bug of round 1)."""
+    src = open(os.path.join(ROOT, "julia", "hip_backend.jl")).read()
+    sigs = _header_signatures()
+    calls = re.findall(r"ccall\(\(:(\w+),\s*LIBSMC\),\s*([\w{}]+),\s*\(([^()]*)\)", src, flags=re.S)
+    assert len(calls) >= 25
+    seen = set()
+    for name, ret, args in calls:
+        assert name in sigs, "ccall to undeclared symbol %s" % name
+        cret, cargs = sigs[name]
+        assert cret in JULIA_TO_C[ret], (name, ret, cret)
+        jargs = [a.strip() for a in args.replace("\n", " ").split(",") if a.strip()]
+        assert len(jargs) == len(cargs), (name, jargs, cargs)
+        for j, c in zip(jargs, cargs):
+            assert c in JULIA_TO_C[j], (name, j, c)
+        seen.add(name)
+    # the entry points a sampler host needs are all bound
+    need = {"smc_create", "smc_destroy", "smc_set_params", "smc_init", "smc_step", "smc_log_likelihood", "smc_get_state",
+            "smc_permute", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_step_window", "smc_step_commit", "smc_normalize",
+            "smc_resample", "smc_get_quantiles", "smc_comm_unique_id", "smc_comm_create", "smc_outer_reweight",
+            "smc_comm_all_gather", "smc_comm_exchange_slots", "smc_last_error"}
+    assert need <= seen, need - seen
+    # definition order: a struct is defined before any method signature or field names it
+    for ty in ("HipFilter", "HipParticles", "HipWeights", "HipSampler", "HipComm"):
+        first_def = re.search(r"^(?:mutable )?struct %s\b" % ty, src, flags=re.M).start()
+        uses = [m.start() for m in re.finditer(r"::%s\b" % ty, src)]
+        assert uses and min(uses) > first_def, ty
+    # AbstractVector contract of the two views: size and getindex for both
+    assert re.search(r"Base\.getindex\(p::HipParticles", src) and re.search(r"Base\.getindex\(w::HipWeights", src)
+    assert re.search(r"Base\.size\(p::Union\{HipParticles,HipWeights\}\)", src)
