@@ -586,8 +586,7 @@ extern "C" int smc_step_commit(smc_handle h, int j) {
     hipLaunchKernelGGL(k_commit, dim3((unsigned)((h->v.ntheta + 127) / 128)), dim3(128), 0, h->stream, h->v, j, h->d_recs);
     HIPCHK(hipGetLastError());
     h->cur ^= 1; h->t += (uint32_t)j; h->emitted = true;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return SMC_OK;
+    return SMC_OK;      // no wait: whatever the caller does next with this handle is ordered behind on its stream
 }
 
 // Filters smc_log_likelihood leaves out (logZ = -inf): the proposals outside the prior's support, for which the
@@ -978,22 +977,47 @@ static int fix_bits_for(int64_t n) {
     return k > FIX_BITS ? FIX_BITS : k;
 }
 
+// Scratch of the stand-alone entry points: device buffers that are released on every way out of the function, and a
+// private non-blocking stream per (host thread, device) so that these calls never serialise against the null stream.
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T* as() const { return (T*)p; }
+};
+hipError_t util_stream(int device, hipStream_t* out) {
+    static thread_local hipStream_t streams[16] = {};
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return e;
+    if (device < 0 || device >= 16) { *out = nullptr; return hipSuccess; }
+    if (!streams[device]) {
+        e = hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = streams[device];
+    return hipSuccess;
+}
+}  // namespace
+
 extern "C" int smc_normalize(const double* logw, int64_t n, double* w, double* logmu, double* ess, int device) {
     if (!logw || !w || n <= 0) return fail(SMC_EINVAL, "smc_normalize: bad argument");
-    HIPCHK(hipSetDevice(device));
-    double *d_in = nullptr, *d_w = nullptr, *d_o = nullptr;
-    HIPCHK(dalloc(&d_in, (size_t)n));
-    HIPCHK(dalloc(&d_w, (size_t)n));
-    HIPCHK(dalloc(&d_o, 2));
-    HIPCHK(hipMemcpy(d_in, logw, (size_t)n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL((k_normalize<1024>), dim3(1), dim3(1024), 0, 0, d_in, n, fix_bits_for(n), d_w, d_o);
+    hipStream_t st = nullptr;
+    HIPCHK(util_stream(device, &st));
+    DevBuf d_in, d_w, d_o;
+    HIPCHK(d_in.alloc((size_t)n * 8));
+    HIPCHK(d_w.alloc((size_t)n * 8));
+    HIPCHK(d_o.alloc(16));
+    HIPCHK(hipMemcpyAsync(d_in.p, logw, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    // one workgroup: the outer reweight works on n_theta-vectors (a few thousand entries)
+    hipLaunchKernelGGL((k_normalize<1024>), dim3(1), dim3(1024), 0, st, d_in.as<double>(), n, fix_bits_for(n), d_w.as<double>(), d_o.as<double>());
     HIPCHK(hipGetLastError());
     double o[2];
-    HIPCHK(hipMemcpy(w, d_w, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(o, d_o, 16, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(w, d_w.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(o, d_o.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     if (logmu) *logmu = o[0];
     if (ess) *ess = o[1];
-    (void)hipFree(d_in); (void)hipFree(d_w); (void)hipFree(d_o);
     return SMC_OK;
 }
 
@@ -1002,47 +1026,44 @@ extern "C" int smc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t 
     if (!w || !a || n <= 0 || ndraw < 0) return fail(SMC_EINVAL, "smc_resample: bad argument");
     if (n > ((int64_t)1 << 31)) return fail(SMC_EINVAL, "smc_resample: n > 2^31");
     if (ndraw == 0) return SMC_OK;
-    HIPCHK(hipSetDevice(device));
-    double* d_w = nullptr;
-    uint64_t* d_C = nullptr;
-    int32_t* d_a = nullptr;
-    int* d_st = nullptr;
-    HIPCHK(dalloc(&d_w, (size_t)n));
-    HIPCHK(dalloc(&d_C, (size_t)n));
-    HIPCHK(dalloc(&d_a, (size_t)ndraw));
-    HIPCHK(dalloc(&d_st, 1));
-    HIPCHK(hipMemcpy(d_w, w, (size_t)n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL((k_resample_cdf<1024>), dim3(1), dim3(1024), 0, 0, d_w, n, fix_bits_for(n), d_C, d_st);
+    hipStream_t st = nullptr;
+    HIPCHK(util_stream(device, &st));
+    DevBuf d_w, d_C, d_a, d_st;
+    HIPCHK(d_w.alloc((size_t)n * 8));
+    HIPCHK(d_C.alloc((size_t)n * 8));
+    HIPCHK(d_a.alloc((size_t)ndraw * 4));
+    HIPCHK(d_st.alloc(4));
+    HIPCHK(hipMemcpyAsync(d_w.p, w, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_resample_cdf<1024>), dim3(1), dim3(1024), 0, st, d_w.as<double>(), n, fix_bits_for(n), d_C.as<uint64_t>(), d_st.as<int>());
     HIPCHK(hipGetLastError());
-    int st = 0;
-    HIPCHK(hipMemcpy(&st, d_st, 4, hipMemcpyDeviceToHost));
-    int rc = SMC_OK;
-    if (st != 0) {
-        rc = fail(SMC_EINVAL, "smc_resample: weights must be finite with a positive maximum");
-    } else {
-        hipLaunchKernelGGL(k_resample_draw, dim3((unsigned)((ndraw + 255) / 256)), dim3(256), 0, 0, d_C, n, ndraw, seed,
-                           stream, t, d_a);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpy(a, d_a, (size_t)ndraw * 4, hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_w); (void)hipFree(d_C); (void)hipFree(d_a); (void)hipFree(d_st);
-    return rc;
+    int status = 0;
+    HIPCHK(hipMemcpyAsync(&status, d_st.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (status != 0) return fail(SMC_EINVAL, "smc_resample: weights must be finite with a positive maximum");
+    hipLaunchKernelGGL(k_resample_draw, dim3((unsigned)((ndraw + 255) / 256)), dim3(256), 0, st, d_C.as<uint64_t>(), n, ndraw, seed,
+                       stream, t, d_a.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(a, d_a.p, (size_t)ndraw * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return SMC_OK;
 }
 
 extern "C" int smc_kalman_log_likelihood(const double* raw, int64_t n_theta, const double* y, int64_t T, int predict_first,
                                          double* out, int device) {
     if (!raw || !y || !out || n_theta <= 0 || T <= 0) return fail(SMC_EINVAL, "smc_kalman_log_likelihood: bad argument");
-    HIPCHK(hipSetDevice(device));
-    double *d_raw = nullptr, *d_y = nullptr, *d_out = nullptr;
-    HIPCHK(dalloc(&d_raw, (size_t)n_theta * 6));
-    HIPCHK(dalloc(&d_y, (size_t)T));
-    HIPCHK(dalloc(&d_out, (size_t)n_theta * 3));
-    HIPCHK(hipMemcpy(d_raw, raw, (size_t)n_theta * 48, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_y, y, (size_t)T * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_kalman, dim3((unsigned)((n_theta + 63) / 64)), dim3(64), 0, 0, d_raw, n_theta, d_y, T, predict_first, d_out);
+    hipStream_t st = nullptr;
+    HIPCHK(util_stream(device, &st));
+    DevBuf d_raw, d_y, d_out;
+    HIPCHK(d_raw.alloc((size_t)n_theta * 48));
+    HIPCHK(d_y.alloc((size_t)T * 8));
+    HIPCHK(d_out.alloc((size_t)n_theta * 24));
+    HIPCHK(hipMemcpyAsync(d_raw.p, raw, (size_t)n_theta * 48, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_y.p, y, (size_t)T * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_kalman, dim3((unsigned)((n_theta + 63) / 64)), dim3(64), 0, st, d_raw.as<double>(), n_theta, d_y.as<double>(), T,
+                       predict_first, d_out.as<double>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(out, d_out, (size_t)n_theta * 24, hipMemcpyDeviceToHost));
-    (void)hipFree(d_raw); (void)hipFree(d_y); (void)hipFree(d_out);
+    HIPCHK(hipMemcpyAsync(out, d_out.p, (size_t)n_theta * 24, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return SMC_OK;
 }
 
@@ -1185,29 +1206,31 @@ extern "C" int smc_sys_targets(uint64_t Dtot, uint32_t n, uint64_t u, uint64_t j
         for (int k = 0; k < nk; ++k) out[k] = sys_target(sb, (uint32_t)k);
         return SMC_OK;
     }
-    HIPCHK(hipSetDevice(device));
-    uint64_t* d = nullptr;
-    HIPCHK(dalloc(&d, (size_t)nk));
-    hipLaunchKernelGGL(k_sys_targets, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, 0, Dtot, n, u, j0, nk, d);
+    hipStream_t st = nullptr;
+    HIPCHK(util_stream(device, &st));
+    DevBuf d;
+    HIPCHK(d.alloc((size_t)nk * 8));
+    hipLaunchKernelGGL(k_sys_targets, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, Dtot, n, u, j0, nk, d.as<uint64_t>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(out, d, (size_t)nk * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d);
+    HIPCHK(hipMemcpyAsync(out, d.p, (size_t)nk * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return SMC_OK;
 }
 
 extern "C" int smc_device_math(int which, const double* a, const double* b, int64_t n, double* out, int device) {
     if (!a || !out || n <= 0 || which < 0 || which > 5) return fail(SMC_EINVAL, "smc_device_math: bad argument");
     if (which >= 3 && !b) return fail(SMC_EINVAL, "smc_device_math: b required");
-    HIPCHK(hipSetDevice(device));
-    double *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIPCHK(dalloc(&da, (size_t)n));
-    HIPCHK(dalloc(&db, (size_t)n));
-    HIPCHK(dalloc(&dout, (size_t)n));
-    HIPCHK(hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
-    if (b) HIPCHK(hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_device_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which, da, db, n, dout);
+    hipStream_t st = nullptr;
+    HIPCHK(util_stream(device, &st));
+    DevBuf da, db, dout;
+    HIPCHK(da.alloc((size_t)n * 8));
+    HIPCHK(db.alloc((size_t)n * 8));
+    HIPCHK(dout.alloc((size_t)n * 8));
+    HIPCHK(hipMemcpyAsync(da.p, a, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (b) HIPCHK(hipMemcpyAsync(db.p, b, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_device_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, which, da.as<double>(), db.as<double>(), n, dout.as<double>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return SMC_OK;
 }

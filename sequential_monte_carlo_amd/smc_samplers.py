@@ -197,13 +197,13 @@ class SMC:
 def _reweight(logw):
     """reweight == normalize (particles.jl:5-15) on an n_theta-vector: host numpy (O(n_theta))."""
     logw = np.asarray(logw, dtype=np.float64)
-    m = np.max(logw)
-    if not np.isfinite(m):
+    m = logw.max()
+    if not math.isfinite(m):
         return -math.inf, np.full(logw.size, 1.0 / logw.size), 0.0
     w = np.exp(logw - m)
-    s = w.sum()
-    w = w / s
-    return m + math.log(s) - math.log(logw.size), w, 1.0 / float(np.sum(w * w))
+    s = float(w.sum())
+    w /= s
+    return m + math.log(s) - math.log(logw.size), w, 1.0 / float(np.dot(w, w))
 
 
 def expected_parameters(smc):
