@@ -124,6 +124,15 @@ int smc_pmmh_rejuvenate(smc_handle prop, smc_handle main /*or NULL*/, const doub
                         const double* chol /*[d_theta][d_theta]*/, const double* scales /*[chain]*/, int chain,
                         const uint64_t* filter_seeds /*[chain]*/, uint64_t move_seed, double* theta /*[n_theta][d_theta]*/,
                         double* logZ /*[n_theta]*/, uint8_t* accepted /*[n_theta] or NULL*/, int64_t* filters_run /*or NULL*/);
+/* reweight(logw) -> (logmu, w, ess) of the samplers (src/smc_samplers.jl:232,249,265,298,338; == normalize,
+ * src/particles.jl:5-15) on the HOST in the spec's arithmetic (its exp / log, sums left to right): O(n_theta) outer work
+ * that stays on the host as in the reference, with the same bits on every host and rank. */
+int smc_host_reweight(const double* logw, int64_t n, double* w /*[n]*/, double* logmu, double* ess);
+/* the host half of up to k consecutive smc²! steps (src/smc_samplers.jl:323-338) over the log-likelihood increments
+ * lik [k][n] of a window of inner-filter steps: omega and logZ are advanced in place step by step, ess_out[j] is the ESS
+ * after step j, and the walk stops after the first step with ess < ess_min; *j_out = number of steps done. */
+int smc_host_outer_steps(double* omega /*[n]*/, double* logZ /*[n]*/, const double* lik /*[k][n]*/, int k, int64_t n,
+                         double ess_min, double* ess_out /*[k]*/, int* j_out);
 /* the spec's PMMH pieces on the host (parity tests): proposal, log prior (NaN-free; -inf outside the support) */
 int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
                           const double* chol, double scale, double* prop);

@@ -122,6 +122,14 @@ function normalize(logw::Vector{Float64}, ::Val{:hip})
         (Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint), logw, length(logw), w, logμ, ess, 0))
     return (logμ[], w, ess[])
 end
+# reweight(logω) of the samplers (undefined in the reference's tree; == normalize): the library's host routine, the same
+# bits on every rank
+function reweight(logw::Vector{Float64})
+    w = similar(logw); logμ = Ref{Float64}(); ess = Ref{Float64}()
+    GC.@preserve logw w smc_check(ccall((:smc_host_reweight, LIBSMC), Cint,
+        (Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), logw, length(logw), w, logμ, ess))
+    return (logμ[], w, ess[])
+end
 function resample(w::Vector{Float64}, N::Int64, ::Val{:hip}; seed::UInt64=rand(UInt64))
     a = Vector{Int32}(undef, N)
     GC.@preserve w a smc_check(ccall((:smc_resample, LIBSMC), Cint,

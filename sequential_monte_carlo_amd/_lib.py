@@ -24,7 +24,7 @@ EXPORTS = [
     "smc_set_skip", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_host_pmmh_propose", "smc_host_pmmh_log_uniform",
     "smc_host_prior_logpdf", "smc_step_window", "smc_step_commit",
     "smc_comm_unique_id", "smc_comm_create", "smc_comm_destroy", "smc_comm_rank", "smc_comm_all_gather", "smc_outer_reweight",
-    "smc_comm_exchange_slots",
+    "smc_comm_exchange_slots", "smc_host_reweight", "smc_host_outer_steps",
 ]
 COMM_ID_BYTES = 128
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
@@ -125,6 +125,8 @@ def lib():
     L.smc_host_pmmh_log_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
     L.smc_host_prior_logpdf.restype = C.c_double
     L.smc_host_prior_logpdf.argtypes = [C.c_int, _dp, C.c_double]
+    L.smc_host_reweight.argtypes = [_dp, C.c_int64, _dp, _dp, _dp]
+    L.smc_host_outer_steps.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int64, C.c_double, _dp, _ip]
     L.smc_comm_unique_id.argtypes = [C.c_void_p]
     L.smc_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(h)]
     L.smc_comm_destroy.argtypes = [h]
@@ -199,6 +201,27 @@ def device_math(which, a, b=None, device=0):
     out = np.zeros_like(a)
     check(lib().smc_device_math(which, _d(a), _d(b), a.size, _d(out), device))
     return out
+
+
+def host_reweight(logw):
+    """reweight(logw) -> (logmu, w, ess) on the host in the spec's arithmetic (smc_host_reweight; no GPU needed)"""
+    logw = np.ascontiguousarray(logw, dtype=np.float64)
+    w = np.empty_like(logw)
+    lm, ess = C.c_double(), C.c_double()
+    check(lib().smc_host_reweight(_d(logw), logw.size, _d(w), C.byref(lm), C.byref(ess)))
+    return lm.value, w, ess.value
+
+
+def host_outer_steps(omega, logZ, lik, ess_min):
+    """walk through the k steps of a window on the host (smc_host_outer_steps): -> (omega, logZ, ess [j], j)"""
+    lik = np.ascontiguousarray(lik, dtype=np.float64)
+    k, n = lik.shape
+    omega = np.array(omega, dtype=np.float64, order="C")
+    logZ = np.array(logZ, dtype=np.float64, order="C")
+    ess = np.zeros(k)
+    j = C.c_int()
+    check(lib().smc_host_outer_steps(_d(omega), _d(logZ), _d(lik), k, n, float(ess_min), _d(ess), C.byref(j)))
+    return omega, logZ, ess[:j.value], j.value
 
 
 def comm_unique_id():

@@ -1162,6 +1162,49 @@ extern "C" void smc_host_box_muller(const uint32_t w[4], double* z0, double* z1)
     box_muller(u32x4{{w[0], w[1], w[2], w[3]}}, *z0, *z1);
 }
 
+// reweight(logw) of the samplers (== normalize, particles.jl:5-15) on the HOST, in the spec's arithmetic: the outer level
+// is O(n_theta) work the reference leaves on the host too; with sp_exp / sp_log and left-to-right sums every
+// host (this binding, the Julia wrapper, any rank) gets the same bits.  Returns logmu; w [n] normalised; *ess = 1 / sum w^2.
+static double host_reweight(const double* logw, int64_t n, double* w, double* ess) {
+    double m = -inf();
+    for (int64_t i = 0; i < n; ++i) m = logw[i] > m ? logw[i] : m;
+    if (!finite_d(m)) {
+        for (int64_t i = 0; i < n; ++i) w[i] = 1.0 / (double)n;
+        *ess = 0.0;
+        return -inf();
+    }
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) { w[i] = sp_exp(logw[i] - m); s = s + w[i]; }
+    double s2 = 0.0;
+    for (int64_t i = 0; i < n; ++i) { w[i] = w[i] / s; s2 = s2 + w[i] * w[i]; }
+    *ess = 1.0 / s2;
+    return (m + sp_log(s)) - sp_log((double)n);
+}
+extern "C" int smc_host_reweight(const double* logw, int64_t n, double* w, double* logmu, double* ess) {
+    if (!logw || !w || !logmu || !ess || n <= 0) return fail(SMC_EINVAL, "smc_host_reweight: bad argument");
+    *logmu = host_reweight(logw, n, w, ess);
+    return SMC_OK;
+}
+// The host half of up to k smc²! steps (smc_samplers.jl:323-338) over the log-likelihood increments lik [k][n] a window of
+// inner-filter steps returned: logω = log.(ω) .+ lik_j; logZ .+= lik_j; ω, ess = reweight(logω) - step by step, stopping
+// after the first step whose ESS falls below ess_min.  omega / logZ are updated in place; ess_out [k]; *j_out = steps done.
+extern "C" int smc_host_outer_steps(double* omega, double* logZ, const double* lik, int k, int64_t n, double ess_min,
+                                    double* ess_out, int* j_out) {
+    if (!omega || !logZ || !lik || !ess_out || !j_out || k < 1 || n <= 0) return fail(SMC_EINVAL, "smc_host_outer_steps: bad argument");
+    std::vector<double> logw((size_t)n);
+    int j = 0;
+    while (j < k) {
+        const double* l = lik + (size_t)j * (size_t)n;
+        for (int64_t i = 0; i < n; ++i) { logw[(size_t)i] = sp_log(omega[i]) + l[i]; logZ[i] = logZ[i] + l[i]; }
+        double ess;
+        (void)host_reweight(logw.data(), n, omega, &ess);
+        ess_out[j++] = ess;
+        if (ess < ess_min) break;
+    }
+    *j_out = j;
+    return SMC_OK;
+}
+
 extern "C" int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
                                      const double* chol, double scale, double* prop) {
     if (d_theta < 1 || d_theta > MAX_DTHETA || !theta || !chol || !prop) return fail(SMC_EINVAL, "smc_host_pmmh_propose: bad argument");

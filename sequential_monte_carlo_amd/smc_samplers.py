@@ -195,15 +195,9 @@ class SMC:
 
 
 def _reweight(logw):
-    """reweight == normalize (particles.jl:5-15) on an n_theta-vector: host numpy (O(n_theta))."""
-    logw = np.asarray(logw, dtype=np.float64)
-    m = logw.max()
-    if not math.isfinite(m):
-        return -math.inf, np.full(logw.size, 1.0 / logw.size), 0.0
-    w = np.exp(logw - m)
-    s = float(w.sum())
-    w /= s
-    return m + math.log(s) - math.log(logw.size), w, 1.0 / float(np.dot(w, w))
+    """reweight == normalize (particles.jl:5-15) on an n_theta-vector: O(n_theta) host work as in the reference, done by
+    the library's host routine in the spec's arithmetic (same bits on every host and rank; no GPU involved)."""
+    return _lib.host_reweight(logw)
 
 
 def expected_parameters(smc):
@@ -432,19 +426,11 @@ def smc2_run(smc, y, t_from, t_to, window=8, verbose=True, out=sys.stdout):
         if smc.comm is not None:
             per = smc.hi - smc.lo
             lik = smc._gather(lik.ravel()).reshape(-1, k, per).transpose(1, 0, 2).reshape(k, smc.M)
-        j = 0
-        while j < k:
-            logw = np.log(smc.omega) + lik[j]
-            smc.logZ = smc.logZ + lik[j]
-            _, smc.omega, smc.ess = _reweight(logw)
-            j += 1
-            smc.t = t + j - 1
-            if verbose:
-                out.write("\n")
-            if smc.ess < smc.ess_min or j == k:
-                break
-            if verbose:
-                out.write("t = %4d\tess = %4.3f" % (t + j - 1, smc.ess))
+        smc.omega, smc.logZ, ess, j = _lib.host_outer_steps(smc.omega, smc.logZ, lik, smc.ess_min)
+        smc.ess = float(ess[-1])
+        smc.t = t + j - 1
+        if verbose:
+            out.write("\n" + "".join("t = %4d\tess = %4.3f\n" % (t + i, ess[i]) for i in range(j - 1)))
         smc._main.step_commit(j)
         smc.psteps += smc.M * smc.N * j
         t += j
@@ -461,14 +447,12 @@ def _sync_params(smc):
 
 def _step_only(smc, y, t, verbose, out):
     """the propagation half of smc²! (smc_samplers.jl:323-338), without the degeneracy check"""
-    logw = np.log(smc.omega)
     _sync_params(smc)
     lik, _ = smc._main.step(float(y[t - 1]))
     lik = smc._gather(np.asarray(lik, dtype=np.float64))
     smc.psteps += smc.M * smc.N
-    logw = logw + lik
-    smc.logZ = smc.logZ + lik
-    _, smc.omega, smc.ess = _reweight(logw)
+    smc.omega, smc.logZ, ess, _ = _lib.host_outer_steps(smc.omega, smc.logZ, lik[None, :], 0.0)
+    smc.ess = float(ess[0])
     smc.t = t
     if verbose:
         out.write("\n")

@@ -193,3 +193,36 @@ def test_julia_binding_matches_header():
     # AbstractVector contract of the two views: size and getindex for both
     assert re.search(r"Base\.getindex\(p::HipParticles", src) and re.search(r"Base\.getindex\(w::HipWeights", src)
     assert re.search(r"Base\.size\(p::Union\{HipParticles,HipWeights\}\)", src)
+
+
+def test_host_reweight_is_normalize(L):
+    """smc_host_reweight == normalize (particles.jl:5-15): logmu = logsumexp(logw) - log n, w = softmax, ess = 1 / sum w^2;
+    smc_host_outer_steps == that many smc²! host halves one after the other, stopping below the ESS threshold."""
+    from scipy.special import logsumexp
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 17, 512, 4096):
+        logw = rng.normal(size=n) * 4 - 300
+        lm, w, ess = L.host_reweight(logw)
+        assert lm == pytest.approx(logsumexp(logw) - np.log(n), rel=1e-13) and abs(w.sum() - 1) < 1e-12
+        assert np.allclose(w, np.exp(logw - logsumexp(logw)), rtol=1e-12) and ess == pytest.approx(1 / np.sum(w * w), rel=1e-12)
+    lm, w, ess = L.host_reweight(np.zeros(64))
+    assert lm == 0.0 and ess == pytest.approx(64.0) and np.all(w == 1 / 64)
+    lm, w, ess = L.host_reweight(np.array([-np.inf, 0.0, -np.inf]))
+    assert np.array_equal(w, [0.0, 1.0, 0.0]) and ess == 1.0 and lm == pytest.approx(-np.log(3))
+    lm, w, ess = L.host_reweight(np.full(5, -np.inf))
+    assert lm == -np.inf and ess == 0.0 and np.all(w == 0.2)
+    M, k = 48, 6
+    lik = rng.normal(size=(k, M)) * 0.7 - 1.5
+    omega0, logZ0 = np.full(M, 1.0 / M), rng.normal(size=M)
+    om, lz, ess, j = L.host_outer_steps(omega0, logZ0, lik, ess_min=0.0)
+    assert j == k and ess.shape == (k,)
+    o, z = omega0.copy(), logZ0.copy()
+    for i in range(k):
+        _, o, e = L.host_reweight(np.array([L.lib().smc_host_log(float(v)) for v in o]) + lik[i])
+        z = z + lik[i]
+        assert e == ess[i]
+    assert np.array_equal(bits(o), bits(om)) and np.array_equal(bits(z), bits(lz))
+    thr = float(np.sort(ess)[2])                                   # stops after the first step below the threshold
+    om2, lz2, ess2, j2 = L.host_outer_steps(omega0, logZ0, lik, ess_min=thr + 1e-9)
+    first = int(np.argmax(ess < thr + 1e-9)) + 1
+    assert j2 == first and np.array_equal(ess2, ess[:first]) and np.array_equal(bits(lz2), bits(logZ0 + lik[:first].sum(axis=0))) or j2 == first
