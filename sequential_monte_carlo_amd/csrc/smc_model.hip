@@ -99,13 +99,13 @@ static hipError_t window_t(const FilterView& v, int T, StepRec* recs, int t0, in
                         : resident_sys_t<THREADS, NP, false, true>(v, T, recs, t0, bin, bout, win, s);
 }
 
-// threads / particle pairs per thread of the LDS-resident kernels for a segment length.  Measured (scripts/res_tune.py):
-// with few filters in flight (<= 4 waves per SIMD at two pairs per thread) the cheap LG model runs faster with one pair
-// per thread (twice the waves); SV / UCSV and large batches prefer two pairs per thread.  SMC_RES_NP (1, 2 or 4) overrides
+// threads / particle pairs per thread of the LDS-resident kernels for a segment length.  Measured (scripts/res_tune.py,
+// scripts/prof_c2.py): with few filters in flight (<= 4 waves per SIMD at two pairs per thread) every model runs faster with
+// one pair per thread (twice the waves: 512 UCSV filters 2.05 -> 1.81 ms); large batches prefer two pairs per thread.  SMC_RES_NP (1, 2 or 4) overrides
 // the choice for tuning runs; results do not depend on it (tests/test_gpu_parity.py::test_launch_geometry_knobs).
 static int resident_np(const FilterView& v) {
     const char* e = getenv("SMC_RES_NP");
-    return e ? atoi(e) : (SMC_MODEL == MODEL_LG1D && v.seg == 1024 && v.ntheta <= 1024) ? 1 : 0;
+    return e ? atoi(e) : (v.seg == 1024 && v.ntheta <= 1024) ? 1 : 0;
 }
 
 template <>
