@@ -429,3 +429,51 @@ def test_density_tempered_docstring_run_weak_pin():
     th = smc.expected_parameters(s)
     assert abs(th[0] - 0.5) < 0.25 and 0.5 < th[1] < 1.6 and 0.6 < th[2] < 1.6
     s.backend.close()
+
+
+def test_full_size_samplers_c4_c5_properties():
+    """BASELINE configs[3] and configs[4] at their per-GPU size (512 x 1024, T = 200, chain 3) on the device path:
+    deterministic replay, the windowed online loop == the step-by-step loop, every proposal outside the prior's support
+    skipped and accounted for, posterior near the simulating parameters, collective-free rejuvenation counts."""
+    import bench
+    T, N, M, chain = 200, 1024, 512, 3
+    # configs[3]: online SMC^2 over the README LG model
+    y, prior, mod, tmap = bench.sampler_setup("smc2")
+    be = smc.smc_samplers.HipBackend()
+
+    def online(window):
+        s = smc.SMC(N, M, mod, prior, chain, 0.5, seed=11, backend=be, theta_map=tmap)
+        smc.smc2(s, y)
+        if window:
+            smc.smc2_run(s, y, 2, T, window=window, verbose=False)
+        else:
+            for t in range(2, T + 1):
+                smc.smc2_step(s, y, t, verbose=False)
+        return s
+
+    a, b, c = online(8), online(0), online(8)
+    for s in (b, c):
+        assert np.array_equal(bits(a.theta), bits(s.theta)) and np.array_equal(bits(a.logZ), bits(s.logZ)) and a.psteps == s.psteps
+    assert a.device_pmmh and a.psteps_skipped > 0 and abs(a.omega.sum() - 1) < 1e-12 and 1 <= a.ess <= M
+    rounds = (a._calls - 1) // (chain + 1)
+    assert rounds >= 3 and a.psteps + a.psteps_skipped >= M * N * T
+    th = smc.expected_parameters(a)
+    assert abs(th[0] - 0.5) < 0.3 and 0.3 < th[1] < 2.0 and 0.3 < th[2] < 2.0          # simulated with (0.5, 0.9, 0.8)
+    assert lg_prior().insupport_many(a.theta).all()
+    be.close()
+    # configs[4]: density_tempered over UCSV with the example's prior
+    y, prior, mod, tmap = bench.sampler_setup("c5dt")
+    be = smc.smc_samplers.HipBackend()
+    runs = []
+    for _ in range(2):
+        s = smc.SMC(N, M, mod, prior, chain, 0.5, seed=5, backend=be, theta_map=tmap)
+        stages = smc.density_tempered(s, y, verbose=False)
+        runs.append((s, stages))
+    (s, stages), (s2, stages2) = runs
+    assert stages == stages2 and np.array_equal(bits(s.theta), bits(s2.theta)) and np.array_equal(bits(s.logZ), bits(s2.logZ))
+    assert stages[-1][0] == 1.0 and all(abs(st[1] - 256.0) < 0.5 for st in stages[:-1]) and 2 <= len(stages) <= 10
+    assert s.psteps + s.psteps_skipped == (1 + chain * (len(stages) - 1)) * M * N * T and s.psteps_skipped > 0
+    assert prior.insupport_many(s.theta).all() and np.all(np.isfinite(s.logZ))
+    th = smc.expected_parameters(s)
+    assert 0.05 < th[0] < 0.6 and 1.0 < th[1] < 5.0                                    # simulated with gamma = 0.2, x0 = 3
+    be.close()
