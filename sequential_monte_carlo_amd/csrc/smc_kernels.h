@@ -628,7 +628,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
     const double y = v.y ? v.y[t] : yval;
-    const int64_t seg0 = (int64_t)sb * SEG;
+    // particle indices fit 32 bits (smc_create: n_x <= 2^31): index arithmetic in 32 bits, 64 bits only in the addresses
+    const uint32_t seg0 = (uint32_t)sb * (uint32_t)SEG, n32 = (uint32_t)v.n;
     const uint64_t* Cprev = v.C[cur] + (size_t)th * v.npad;
     const double* xprev = v.x[cur];
     uint64_t* scr;
@@ -663,12 +664,12 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     }
     // this thread's child indices relative to the workgroup's first child (masked children j >= n take
     // the last real child's target: they are never stored as real particles)
-    const int64_t m_blk = (seg0 + SEG < v.n ? seg0 + SEG : v.n) - seg0;   // children of this block (>= 1)
+    const uint32_t m_blk = (seg0 + SEG < n32 ? seg0 + SEG : n32) - seg0;   // children of this block (>= 1)
     uint32_t kk[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        const int64_t j = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
-        kk[i] = (uint32_t)((j < v.n ? j : v.n - 1) - seg0);
+        const uint32_t j = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+        kk[i] = (j < n32 ? j : n32 - 1) - seg0;
     }
     uint64_t Tg[NQ];   // MULTI: the children's targets in table units; after the segment lookup, the in-segment thresholds
 
@@ -742,9 +743,9 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         SysBase sbase{};
         uint64_t Tfirst, Tlast, lo_ = 0;
         if (SYS) {
-            sbase = sys_base(alive, (uint32_t)v.n, v.inv_n, sysw[0], (uint64_t)seg0);
+            sbase = sys_base(alive, n32, v.inv_n, sysw[0], (uint64_t)seg0);
             Tfirst = sys_target(sbase, 0u);
-            Tlast = sys_target(sbase, (uint32_t)(m_blk - 1));
+            Tlast = sys_target(sbase, m_blk - 1);
         } else {
             mul64wide(F0, alive, Tfirst, lo_);
             mul64wide(F1, alive, Tlast, lo_);
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             } else {   // the block's largest uniform is its break point; the others are iid below it
                 uint64_t pick;
                 mul64wide(rr[i], Tlast - Tfirst, pick, lo_);
-                Tg[i] = (int64_t)kk[i] == m_blk - 1 ? Tlast : Tfirst + pick;
+                Tg[i] = kk[i] == m_blk - 1 ? Tlast : Tfirst + pick;
             }
             pos[i] = b_lo;
         }
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             const int sh = seg_shift(0.0, 0.0, v.SH);
             const uint64_t Dtot = seg_Q(alive, sh);
             const u32x4 uw = draw(v.seed, 0u, stream, t, SLOT_SYS);
-            const SysBase sbase = sys_base(Dtot, (uint32_t)v.n, v.inv_n, ((uint64_t)uw.v[1] << 32) | uw.v[0], 0u);
+            const SysBase sbase = sys_base(Dtot, n32, v.inv_n, ((uint64_t)uw.v[1] << 32) | uw.v[0], 0u);
 #pragma unroll
             for (int i = 0; i < NQ; ++i) Tg[i] = sys_threshold(sys_target(sbase, kk[i]), sh);
             alive = Dtot;
@@ -917,14 +918,14 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         for (int i = 0; i < NQ; ++i) pos[i] = lds_unpad((int)(pb[i] - lds_ptr(Cst)) >> 3);
     }
     SMC_STAMP(v, 5);
-    int64_t anc[NQ];
+    uint32_t anc[NQ];
     double xp[NQ][D];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-        const int64_t own = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
-        int64_t a = (int64_t)bseg[i] * SEG + pos[i];
+        const uint32_t own = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+        uint32_t a = (uint32_t)bseg[i] * (uint32_t)SEG + (uint32_t)pos[i];
         a = alive ? a : own;                // collapsed filter: identity
-        a = a < v.n ? a : v.n - 1;          // only masked children (j >= n) can land there
+        a = a < n32 ? a : n32 - 1;          // only masked children (j >= n) can land there
         anc[i] = a;
 #pragma unroll
         for (int c = 0; c < D; ++c) xp[i][c] = SMC_ABL(v, 1) ? 0.25 * (double)(a & 7) : xprev[((size_t)c * v.ntheta + th) * v.npad + a];
@@ -934,7 +935,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     double lw[NP][2];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const int64_t i0 = seg0 + 2 * (tid + k * THREADS);
+        const uint32_t i0 = seg0 + 2 * (tid + k * THREADS);
         double xn[2][D];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -942,14 +943,14 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 #pragma unroll
             for (int c = 0; c < D; ++c) zz[c] = z[k][c][j];
             model_transition<MODEL>(prm, xp[2 * k + j], zz, xn[j]);
-            const bool valid = (i0 + j) < v.n;
+            const bool valid = (i0 + j) < n32;
             lw[k][j] = valid ? model_logobs<MODEL>(prm, xn[j], y) : nan_mask();
         }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             double2 o;
-            o.x = (i0 < v.n) ? xn[0][c] : 0.0;
-            o.y = (i0 + 1 < v.n) ? xn[1][c] : 0.0;
+            o.x = (i0 < n32) ? xn[0][c] : 0.0;
+            o.y = (i0 + 1 < n32) ? xn[1][c] : 0.0;
             store_out(reinterpret_cast<double2*>(v.x[nxt] + ((size_t)c * v.ntheta + th) * v.npad + i0), o);
         }
         if (v.anc) {
