@@ -142,15 +142,18 @@ class Ctx:
     def max_over_ranks(self, seconds):
         if self.dist is None:
             return seconds
-        tt = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda" if self.on_gpu else "cpu")
+        tt = self.torch.tensor([seconds], dtype=self.torch.float64,
+                               device=self.torch.device("cuda", self.local_rank) if self.on_gpu else "cpu")
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
 
     def barrier(self):
         if self.dist is not None:
             if self.on_gpu:
-                self.torch.cuda.synchronize()
-            self.dist.barrier()
+                self.torch.cuda.synchronize(self.local_rank)
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
 
 
 def main(argv=None):
@@ -364,6 +367,8 @@ def run_aux(args, ctx, timeout_s=300.0):
     res = {}
 
     def work():
+        if ctx.on_gpu:
+            ctx.torch.cuda.set_device(ctx.local_rank)     # the current device is per thread: collectives and barriers use it
         for algo in ("smc2", "c5dt"):
             try:
                 r = bench_sampler(args, ctx, algo, "strong", steps=2, warmup=1)

@@ -12,6 +12,7 @@ class ThetaComm:
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
+        self._bufs = {}
 
     def slice(self, M):
         if M % self.world:
@@ -20,13 +21,26 @@ class ThetaComm:
         return self.rank * per, (self.rank + 1) * per
 
     def all_gather(self, local):
+        """every rank's `local` (equal lengths), concatenated in rank order, on every rank.  The device and pinned
+        staging buffers are kept per length: a sampler run makes dozens of these tiny latency-bound exchanges."""
         import torch
-        t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
-        if self.device is not None:
-            t = t.to(self.device)
-        out = torch.empty(t.numel() * self.world, dtype=torch.float64, device=t.device)
-        self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy()          # .cpu() synchronises with the collective
+        src = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64).ravel())
+        n = src.numel()
+        if self.device is None:
+            out = torch.empty(n * self.world, dtype=torch.float64)
+            self.dist.all_gather_into_tensor(out, src)
+            return out.numpy()
+        bufs = self._bufs.get(n)
+        if bufs is None:
+            bufs = (torch.empty(n, dtype=torch.float64, device=self.device),
+                    torch.empty(n * self.world, dtype=torch.float64, device=self.device),
+                    torch.empty(n * self.world, dtype=torch.float64).pin_memory())
+            self._bufs[n] = bufs
+        send, recv, host = bufs
+        send.copy_(src)
+        self.dist.all_gather_into_tensor(recv, send)
+        host.copy_(recv)                  # a device-to-host copy on the current stream: waits for the collective
+        return host.numpy().copy()
 
 
     # ---- online SMC^2 with sharded theta: resample!(smc) moves whole filters between ranks ---------------
