@@ -277,7 +277,7 @@ struct TableLds {
     uint64_t* scr;   // scratch
 };
 __host__ __device__ inline size_t scr_words(int threads, int np) {
-    return (size_t)((np + 3 > 4 ? np + 3 : 4) * (threads / WAVE) + 8);   // [red | wave totals ...]
+    return (size_t)((np + 3 > 4 ? np + 3 : 4) * (threads / WAVE) + 16);   // [red | wave totals ... | 8 window words | 8 tail words]
 }
 __host__ __device__ inline size_t table_lds_bytes(int nseg_p2, int threads, int np) {
     return (size_t)nseg_p2 * 16 + scr_words(threads, np) * 8;   // sh padded to 8 B per entry
@@ -402,6 +402,58 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
         }
     }
     __syncthreads();
+    return Dtot;
+}
+
+// Window prologue: what a workgroup of k_step needs from the segment table in the usual case - the total Dtot and the
+// entries Dcum[lo-1], Dcum[lo .. lo+NE-1], sh[lo .. lo+NE-1] of its speculative window - WITHOUT building the table in LDS:
+// one record per thread (nseg_p2 <= THREADS), the exponent maximum, one wave scan of the Q_b, the wave totals, and the NE + 1
+// values picked out of the lanes that hold them.  Two barriers (the full prologue: three, plus the table traffic).  The
+// numbers are the same integers table_prologue produces.  P0 = Dcum[lo-1] (0 for lo = 0), Dc[r] = Dcum[lo+r].
+template <int THREADS, int NE>
+__device__ __forceinline__ uint64_t window_prologue(const FilterView& v, uint64_t* scr, const TablePre& pre, int lo, uint64_t& P0,
+                                                    uint64_t (&Dc)[NE], int (&shw)[NE]) {
+    constexpr int NW = THREADS / WAVE;
+    constexpr int DEADK = (int)0x80000000;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const bool live = tid < v.nseg;
+    const int ki = (!live || pre.k1 == -inf()) ? DEADK : (int)pre.k1;
+    const int km = block_max_i32<THREADS>(ki, (int*)scr);            // barrier 1
+    const double K = km == DEADK ? -inf() : (double)km;
+    int sh = 64;
+    uint64_t Q = 0;
+    if (live) { sh = seg_shift(K, pre.k1, v.SH); Q = seg_Q(pre.S1, sh); }
+    const uint64_t incl = wave_incl_scan(Q, lane);
+    static_assert(2 * NE + 1 <= 8, "window words");
+    uint64_t* wt = scr + NW;              // [NW] wave totals
+    uint64_t* slot = scr + scr_words(THREADS, 1) - 16;   // the 8 window words (the same place for every NP: 4*NW + 0..7):
+                                          // [0]: inclusive sum (inside its wave) at segment lo-1; [1..NE]: Q; [NE+1 .. 2NE]: sh
+    if (lane == WAVE - 1) wt[wave] = incl;
+    if (tid == lo - 1) slot[0] = incl;
+    const int r = tid - lo;
+    if (r >= 0 && r < NE) { slot[1 + r] = Q; slot[1 + NE + r] = (uint64_t)(uint32_t)sh; }
+    __syncthreads();                                                 // barrier 2
+    // totals of the waves: lanes 0..NW-1 of every wave scan them (DPP), Dtot and the offset of the wave holding segment lo-1
+    uint64_t t = wt[lane & (NW - 1)];
+    if (NW > 1) t += dpp_u64z<0x111, 0xf>(t);
+    if (NW > 2) t += dpp_u64z<0x112, 0xf>(t);
+    if (NW > 4) t += dpp_u64z<0x114, 0xf>(t);
+    if (NW > 8) t += dpp_u64z<0x118, 0xf>(t);
+    const uint64_t Dtot = readlane_u64(t, NW - 1);
+    uint64_t p0 = 0;
+    if (lo > 0) {                                                    // workgroup-uniform
+        const int ws = __builtin_amdgcn_readfirstlane((lo - 1) / WAVE);
+        const uint64_t before = ws > 0 ? readlane_u64(t, ws - 1) : 0;
+        p0 = before + slot[0];
+    }
+    P0 = p0;
+    uint64_t run = p0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        run += slot[1 + i];
+        Dc[i] = run;
+        shw[i] = (int)(uint32_t)slot[1 + NE + i];
+    }
     return Dtot;
 }
 
@@ -734,8 +786,16 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             const u32x4 uw = draw(v.seed, 0u, stream, t, SLOT_SYS);
             sysw[0] = ((uint64_t)uw.v[1] << 32) | uw.v[0];
         }
-        // the segment table of the weights being resampled; workgroup 0 of the filter emits (logmu, ess)
-        alive = table_prologue<THREADS>(v, cur, th, L, emit_prev && sb == 0, t == 1u, t - 1u, &tpre);
+        // What this workgroup needs of the segment table of the weights being resampled.  Usual case: only its speculative
+        // window (window_prologue: no table in LDS).  The workgroup that emits (logmu, ess) of the previous step, filters with
+        // more segments than threads, and windows that turn out too narrow build the whole table (table_prologue).
+        const bool emitter = emit_prev && sb == 0;
+        const int s_hi = spec_lo + NSTAGE - 1 < v.nseg - 1 ? spec_lo + NSTAGE - 1 : v.nseg - 1;
+        const bool use_fast = SPEC && !emitter && v.nseg_p2 <= THREADS;      // workgroup-uniform
+        uint64_t P0 = 0, Dc[NSTAGE];
+        int shw[NSTAGE];
+        if (use_fast) alive = window_prologue<THREADS, NSTAGE>(v, L.scr, tpre, spec_lo, P0, Dc, shw);
+        else alive = table_prologue<THREADS>(v, cur, th, L, emitter, t == 1u, t - 1u, &tpre);
         SMC_STAMP(v, 1);
         SMC_PRIO(1);
         // targets of the first and last child of the block, in table units.  multinomial: the block's n
@@ -751,10 +811,14 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             mul64wide(F1, alive, Tlast, lo_);
         }
         // targets lie in [Tfirst, Tlast]: the workgroup's ancestors are the segments [b_lo, b_hi] of these two.
-        // Usual case: both inside the speculative window - two table reads settle it.
+        // Usual case: both inside the speculative window.
+        bool fast = false;
+        if (use_fast) {
+            fast = (spec_lo == 0 || P0 <= Tfirst) && Tlast < Dc[s_hi - spec_lo];
+            if (!fast) alive = table_prologue<THREADS>(v, cur, th, L, false, false, 0u, &tpre);   // rare: very uneven weights
+        }
         int b_lo = 0, b_hi = 0;
-        const int s_hi = spec_lo + NSTAGE - 1 < v.nseg - 1 ? spec_lo + NSTAGE - 1 : v.nseg - 1;
-        if (SPEC && (spec_lo == 0 || L.Dcum[spec_lo - 1] <= Tfirst) && Tlast < L.Dcum[s_hi]) {
+        if (fast || (SPEC && !use_fast && (spec_lo == 0 || L.Dcum[spec_lo - 1] <= Tfirst) && Tlast < L.Dcum[s_hi])) {
             b_lo = spec_lo;      // a superset of the true range is as good: children search inside it
             b_hi = s_hi;
         } else {
@@ -800,19 +864,38 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             }
             pos[i] = b_lo;
         }
-        for (int s = w0 >> 1; s >= 1; s >>= 1) {
+        if (fast) {   // the window's three entries sit in registers: two comparisons place a child
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                const int c = pos[i] + s;
-                pos[i] = (c <= b_hi && L.Dcum[c - 1] <= Tg[i]) ? c : pos[i];
-            }
-        }
+                int r = 0;
+                uint64_t base = P0;
+                int shc = shw[0];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            bseg[i] = pos[i];
-            Sseg[i] = 0;
-            const uint64_t base = bseg[i] ? L.Dcum[bseg[i] - 1] : 0;
-            Tg[i] = sys_threshold(Tg[i] - base, L.sh[bseg[i]]);   // (C >> sh) > T - base  <=>  C > threshold
+                for (int k = 0; k + 1 < NSTAGE; ++k) {
+                    const bool up = Dc[k] <= Tg[i];
+                    r += up ? 1 : 0;
+                    base = up ? Dc[k] : base;
+                    shc = up ? shw[k + 1] : shc;
+                }
+                bseg[i] = spec_lo + r;
+                Sseg[i] = 0;
+                Tg[i] = sys_threshold(Tg[i] - base, shc);   // (C >> sh) > T - base  <=>  C > threshold
+            }
+        } else {
+            for (int s = w0 >> 1; s >= 1; s >>= 1) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const int c = pos[i] + s;
+                    pos[i] = (c <= b_hi && L.Dcum[c - 1] <= Tg[i]) ? c : pos[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                bseg[i] = pos[i];
+                Sseg[i] = 0;
+                const uint64_t base = bseg[i] ? L.Dcum[bseg[i] - 1] : 0;
+                Tg[i] = sys_threshold(Tg[i] - base, L.sh[bseg[i]]);   // (C >> sh) > T - base  <=>  C > threshold
+            }
         }
     } else {
         const TableLds L = carve(smem, v.nseg_p2);
