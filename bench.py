@@ -245,8 +245,8 @@ def bench_filter(args, ctx):
             units = float(nth) * nx * T
             kname = "k_resident"
         else:
-            # HIP-event brackets around runs of 8 consecutive k_step launches, averaged per launch
-            avg_ms, min_ms = h.time_step_kernel(y[: min(T, 600)], nsample=64)
+            # HIP-event brackets around runs of 32 consecutive k_step launches, averaged per launch
+            avg_ms, min_ms = h.time_step_kernel(y[: min(T, 1000)], nsample=24)
             ovh = h.event_overhead_ms(64)          # what an empty event bracket reads (reported, NOT subtracted)
             ms = avg_ms
             units = float(nth) * nx
@@ -279,8 +279,8 @@ def bench_filter(args, ctx):
             except Exception:   # noqa: BLE001
                 pass
         if not h.resident:
-            roof["empty_event_bracket_ms"] = round(ovh, 6)   # an event pair's own cost, spread over the 8 launches of a bracket
-            roof["launches_per_bracket"] = 8
+            roof["empty_event_bracket_ms"] = round(ovh, 6)   # an event pair's own cost, spread over the launches of a bracket
+            roof["launches_per_bracket"] = 32 if min(T, 1000) - 1 >= 512 else 8
 
     # ---- CPU baseline: the oracle (scalar port of particles.jl), bounded sample -----------------
     cpu = None

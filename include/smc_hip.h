@@ -176,7 +176,7 @@ int smc_get_geometry(smc_handle h, int* seg, int* nseg, int* d, int* resident);
 int smc_last_elapsed_ms(smc_handle h, double* ms);
 int smc_synchronize(smc_handle h);
 /* roofline measurement: runs log_likelihood through the one-launch-per-step path and brackets
- * `nsample` evenly spaced runs of 8 consecutive k_step launches (one launch when T < 65) with HIP events
+ * `nsample` evenly spaced runs of 32 consecutive k_step launches (8 when T < 513, one when T < 65) with HIP events
  * on the handle's stream; returns the average / minimum bracketed duration PER k_step launch in ms. */
 int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, int nsample, double* avg_ms, double* min_ms);
 /* what an EMPTY HIP-event bracket measures on the handle's stream (average of nsample brackets with a

@@ -743,7 +743,7 @@ extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, in
     if (rc) return rc;
     // a bracket spans G consecutive k_step launches (a step IS one launch): the ~5 us an event pair costs on
     // this stack is amortised over the G launches instead of being charged to one
-    const int G = T - 1 >= 64 ? 8 : 1;
+    const int G = T - 1 >= 512 ? 32 : (T - 1 >= 64 ? 8 : 1);
     if ((int64_t)nsample * G > T - 1) nsample = (int)((T - 1) / G);
     std::vector<hipEvent_t> e0((size_t)nsample), e1((size_t)nsample);
     for (int i = 0; i < nsample; ++i) { HIPCHK(hipEventCreate(&e0[i])); HIPCHK(hipEventCreate(&e1[i])); }
