@@ -16,6 +16,6 @@ else:
     m, raw = (1, LG) if wl == "c4" else (3, UC)
     _, y = L.simulate(m, raw, T, 1998)
     h = L.Handle(m, 512, 1024, seed=1); h.set_params(np.tile(raw, (512, 1)))
-h.log_likelihood(y[:10])
+h.log_likelihood(y)
 z = h.log_likelihood(y)
 print("logZ", z[0], "ms", h.elapsed_ms(), "p-steps/s %.3e" % (h.n_theta * h.n_x * T / h.elapsed_ms() * 1e3))
