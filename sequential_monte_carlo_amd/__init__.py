@@ -10,6 +10,6 @@ from .kalman_filter import log_likelihood_kalman  # noqa: F401
 from .models import (UCSV, LinearModel, StateSpaceModel, StochasticVolatility, UnivariateLinearGaussian,  # noqa: F401
                      simulate, unobserved_components, unobserved_components_stochastic_volatility)
 from .particles import (bootstrap_filter, bootstrap_filter_, log_likelihood, normalize, resample, reweight)  # noqa: F401
-from .smc_samplers import (SMC, ThetaMap, density_tempered, expected_parameters, rejuvenate_, resample_, smc2, smc2_run, smc2_step)  # noqa: F401
+from .smc_samplers import (SMC, ThetaMap, density_tempered, estimated_trend, expected_parameters, filtered_summaries, rejuvenate_, resample_, smc2, smc2_run, smc2_step)  # noqa: F401
 
 __version__ = "0.1.0"

@@ -206,6 +206,48 @@ def expected_parameters(smc):
     return (smc.theta * w[:, None]).sum(axis=0)
 
 
+def _per_theta(smc, local):
+    """[M_local, k] rows of per-filter summaries of this rank -> [M, k] on every rank"""
+    local = np.ascontiguousarray(local, dtype=np.float64)
+    if smc.comm is None:
+        return local
+    k = local.shape[1]
+    return smc._gather(local.ravel()).reshape(smc.M, k)
+
+
+def filtered_summaries(smc, p=(0.25, 0.5, 0.75), component=0):
+    """(quantiles [len(p)], variance) of the filtered state of the online sampler, integrated over the parameter particles:
+    per theta-particle the weighted quantiles and variance of its x cloud, then their omega-weighted means - what
+    get_quantiles_uc / get_quantiles_ucsv compute every period in examples/inflation_example.jl:39-55,239-252.
+    The per-filter summaries are computed on the device (smc_get_quantiles / smc_get_moments): no cloud leaves the GPU."""
+    if smc._main is None:
+        raise ValueError("filtered_summaries needs the online sampler's filters (call smc2 first)")
+    q = np.asarray(smc._main.quantiles(list(p), component))            # [M_local][len(p)]
+    _, var = smc._main.moments()                                       # [d][M_local]
+    allq = _per_theta(smc, np.column_stack([q, np.asarray(var)[component]]))
+    w = smc.omega / smc.omega.sum()
+    return w @ allq[:, :-1], float(w @ allq[:, -1])
+
+
+def estimated_trend(smc):
+    """estimated_trend(smc)   src/plotting_utils.jl:116-124:  sum_m omega[m] * mean(observation(model(theta[m]), w[m]' x[m])).
+    The filtered means w[m]' x[m] come from the device; mean(observation(.)) is B x for the linear model (ssm.jl:96-103),
+    x[1] for UCSV (:244-247) and 0 for the stochastic-volatility model."""
+    if smc._main is None:
+        raise ValueError("estimated_trend needs the online sampler's filters (call smc2 first)")
+    mean, _ = smc._main.moments()                                      # [d][M_local]
+    mid, rows = _rows(smc._models(smc.theta[smc.lo:smc.hi]))
+    if mid == _lib.MODEL_LG1D:
+        obs = rows[:, 1] * np.asarray(mean)[0]
+    elif mid == _lib.MODEL_UCSV3D:
+        obs = np.asarray(mean)[0]
+    else:
+        obs = np.zeros(rows.shape[0])
+    allobs = _per_theta(smc, obs[:, None])[:, 0]
+    w = smc.omega / smc.omega.sum()
+    return float(w @ allobs)
+
+
 def resample_(smc):
     """resample!(smc)   smc_samplers.jl:74-84 -- value-copy semantics."""
     w = smc.omega / smc.omega.sum()

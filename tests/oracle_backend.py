@@ -77,6 +77,13 @@ class OracleHandle:
         for k, i in enumerate(idx):
             self.f[int(i)].import_state(arr[k])
 
+    def moments(self):
+        r = [f.moments() for f in self.f]
+        return np.stack([a for a, _ in r], axis=1), np.stack([b for _, b in r], axis=1)          # [d][n_theta]
+
+    def quantiles(self, p, component=0):
+        return np.stack([f.quantiles(p, component) for f in self.f])                             # [n_theta][len(p)]
+
     def state(self):
         xs = [f.state() for f in self.f]
         return np.stack([x[0] for x in xs], axis=1), np.stack([x[1] for x in xs]), None

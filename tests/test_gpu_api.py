@@ -477,3 +477,18 @@ def test_full_size_samplers_c4_c5_properties():
     th = smc.expected_parameters(s)
     assert 0.05 < th[0] < 0.6 and 1.0 < th[1] < 5.0                                    # simulated with gamma = 0.2, x0 = 3
     be.close()
+
+
+def test_filtered_summaries_on_gpu_equal_oracle_backend():
+    """filtered_summaries / estimated_trend (examples/inflation_example.jl:39-55, plotting_utils.jl:116-124): the device
+    quantiles are bit-identical to the oracle's, the moments agree to rounding (different summation order)."""
+    out = []
+    for backend in (smc.smc_samplers.HipBackend(), OracleBackend()):
+        _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 12, seed=1998)
+        s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, seed=7, backend=backend, theta_map=LG_TMAP)
+        smc.smc2(s, y)
+        smc.smc2_run(s, y, 2, 12, window=4, verbose=False)
+        out.append((smc.filtered_summaries(s, [0.1, 0.5, 0.9]), smc.estimated_trend(s)))
+    (qh, vh), th = out[0]
+    (qo, vo), to = out[1]
+    assert np.array_equal(bits(qh), bits(qo)) and vh == pytest.approx(vo, rel=1e-10) and th == pytest.approx(to, rel=1e-10)

@@ -280,3 +280,22 @@ def test_theta_sharding_world_size_2_gloo(tmp_path):
         xs = np.concatenate([p_[head.size:head.size + d * (M // 2) * N].reshape(d, M // 2, N) for p_ in parts], axis=1)
         ws = np.concatenate([p_[head.size + d * (M // 2) * N:].reshape(M // 2, N) for p_ in parts], axis=0)
         assert np.array_equal(xs, x) and np.array_equal(ws, w), device
+
+
+def test_filtered_summaries_and_trend():
+    """get_quantiles_* of examples/inflation_example.jl:39-55 and estimated_trend of plotting_utils.jl:116-124 over the
+    online sampler: per-filter weighted quantiles / variance / mean, integrated over the parameter particles."""
+    s, _, x, w = run_online(T=12)
+    q, var = smc.filtered_summaries(s, [0.25, 0.5, 0.75])
+    om = s.omega / s.omega.sum()
+    means = np.einsum("mn,mn->m", w, x[0])
+    per_var = np.einsum("mn,mn->m", w, x[0] ** 2) - means ** 2
+    assert var == pytest.approx(float(om @ per_var), rel=1e-9) and q.shape == (3,) and q[0] <= q[1] <= q[2]
+    # the per-filter quantile is the inverse of the weighted empirical CDF: check against a sort-based evaluation
+    ref = []
+    for m in range(s.M):
+        o = np.argsort(x[0, m], kind="stable")
+        cw = np.cumsum(w[m][o])
+        ref.append([x[0, m][o][min(np.searchsorted(cw, pp, side="right"), x.shape[2] - 1)] for pp in (0.25, 0.5, 0.75)])
+    assert np.allclose(q, om @ np.array(ref), atol=0.05)
+    assert smc.estimated_trend(s) == pytest.approx(float(om @ (1.0 * means)), rel=1e-9)      # B = 1 in lg_mod
