@@ -20,8 +20,16 @@ __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int n
 // every step go to `win` ([2][T][ntheta], pinned host memory) - nothing else of the handle changes (logZ and the
 // "last emitted" values are advanced by k_commit once the host has decided to keep the steps).  This is the
 // speculative multi-step call of the online sampler (smc_step_window): bootstrap_filter! k times in one launch.
+// Waves per SIMD the register budget must allow (second launch bound).  Only the 512-thread, one-pair-per-thread variant
+// (1024-particle filters: the samplers' shape) is pinned - to 4, i.e. two workgroups per CU: there a 129th vector register
+// halves the occupancy (measured: 512 UCSV filters 1.69 -> 2.24 ms).  Pinning the larger variants the same way makes the
+// compiler spill and costs more than the occupancy gains (2048 particles, UCSV: 1.07 -> 1.40 ms), so they keep the default.
+template <int MODEL, int THREADS, int NP>
+constexpr int resident_min_waves() {
+    return (THREADS == 512 && NP == 1) ? 4 : 1;
+}
 template <int MODEL, int THREADS, int NP, bool SYS = false, bool WIN = false>
-__global__ __launch_bounds__(THREADS) void k_resident(FilterView v, int T, StepRec* recs /*[ntheta][T]*/, int t0, int bin, int bout,
+__global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())) void k_resident(FilterView v, int T, StepRec* recs /*[ntheta][T]*/, int t0, int bin, int bout,
                                                       double* win) {
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;

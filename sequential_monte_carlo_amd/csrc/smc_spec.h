@@ -168,14 +168,10 @@ SMC_HD uint64_t fix_weight_i(double p, int dk, int bits) {
     return d2bits(p * pow2i(bits + dk) + 0x1p52) & 0x000fffffffffffffULL;
 }
 
-SMC_HD double sp_log(double x) {
-    if (x != x || x < 0.0) return bits2d(0x7ff8000000000000ULL);
-    if (x == 0.0) return -inf();
-    if (x == inf()) return x;
-    int e = 0;
-    if (x < 0x1p-1022) { x *= 0x1p54; e = -54; }
+// log(x) for x positive, finite and normal (no special cases to test): the body of sp_log
+SMC_HD double sp_log_normal(double x, int e0) {
     const uint64_t b = d2bits(x);
-    e += (int)((b >> 52) & 0x7ff) - 1023;
+    int e = e0 + (int)((b >> 52) & 0x7ff) - 1023;
     double m = bits2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
     if (m > SQRT2) { m *= 0.5; e += 1; }
     const double f = m - 1.0;
@@ -195,6 +191,15 @@ SMC_HD double sp_log(double x) {
     R = R * z;
     const double dk = (double)e;
     return dk * LN2_HI - ((s * (f - R) - dk * LN2_LO) - f);
+}
+
+SMC_HD double sp_log(double x) {
+    if (x != x || x < 0.0) return bits2d(0x7ff8000000000000ULL);
+    if (x == 0.0) return -inf();
+    if (x == inf()) return x;
+    int e = 0;
+    if (x < 0x1p-1022) { x *= 0x1p54; e = -54; }
+    return sp_log_normal(x, e);
 }
 
 // cos, sin of 2*pi*u for u in [0,1) a multiple of 2^-53
@@ -239,7 +244,7 @@ SMC_HD void box_muller(const u32x4& w, double& z0, double& z1) {
     const uint64_t n2 = (((uint64_t)w.v[3] << 32) | w.v[2]) >> 11;
     const double u1 = (double)(n1 + 1) * TWO_M53;
     const double u2 = (double)n2 * TWO_M53;
-    const double r = sqrt(-2.0 * sp_log(u1));
+    const double r = sqrt(-2.0 * sp_log_normal(u1, 0));   // u1 in [2^-53, 1]: positive, finite, normal
     double c, s;
     sp_sincos2pi(u2, c, s);
     z0 = r * c;
