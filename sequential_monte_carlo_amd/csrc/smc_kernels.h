@@ -505,7 +505,7 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
             // fix_weight_i(p, k - kb, FIX_BITS), branch-free (same value: the clamp only acts where q = 0)
             const int dk = (kk[k][j] != DEAD) ? kk[k][j] - kbi : -1024;
             const int ek = dk > -(FIX_BITS + 8) ? FIX_BITS + dk : -8;
-            const uint64_t qv = d2bits(p[k][j] * pow2i(ek) + 0x1p52) & 0x000fffffffffffffULL;
+            const uint64_t qv = d2bits(scale2(p[k][j], ek) + 0x1p52) & 0x000fffffffffffffULL;
             const uint64_t qq = dk >= -(FIX_BITS + 2) ? qv : 0;
             q[k][j] = qq;
             if (want_s2) s2 = add128(s2, sq128(qq));
@@ -523,10 +523,27 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     if (lane == 0) { w2[wave] = s2.lo; w2[NW + wave] = s2.hi; }
     __syncthreads();
     uint64_t basek = 0;
+    // prefix of this wave's slice in the order (k, wave) - the order of the particles.  All NP*NW totals fit one row of 16
+    // lanes in the usual geometries: ONE DPP scan gives every (k, wave) offset and the segment total
+    constexpr bool MERGED = NP > 1 && NP * NW <= 16;
+    uint64_t tt = 0;
+    if (MERGED) {
+        tt = wtot[lane & (NP * NW - 1)];
+        tt += dpp_u64z<0x111, 0xf>(tt);
+        if (NP * NW > 2) tt += dpp_u64z<0x112, 0xf>(tt);
+        if (NP * NW > 4) tt += dpp_u64z<0x114, 0xf>(tt);
+        if (NP * NW > 8) tt += dpp_u64z<0x118, 0xf>(tt);
+    }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         uint64_t off, ktot;
-        wave_totals<NW>(wtot + k * NW, lane, wave, off, ktot);
+        if (MERGED) {
+            const int j = __builtin_amdgcn_readfirstlane(k * NW + wave);
+            off = j > 0 ? readlane_u64(tt, j > 0 ? j - 1 : 0) : 0;     // everything before (k, wave): basek is inside
+            ktot = 0;
+        } else {
+            wave_totals<NW>(wtot + k * NW, lane, wave, off, ktot);
+        }
         const uint64_t excl = basek + off + incl[k] - ps[k];
         ulonglong2 cc;
         cc.x = excl + q[k][0];
@@ -535,6 +552,7 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
         else store_out(reinterpret_cast<ulonglong2*>(Cout + 2 * (tid + k * THREADS)), cc);
         basek += ktot;
     }
+    if (MERGED) basek = readlane_u64(tt, NP * NW - 1);
     SegRec rec;
     rec.kb = kb;
     rec.S = basek;

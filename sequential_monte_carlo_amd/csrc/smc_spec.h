@@ -55,6 +55,15 @@ SMC_HD int model_nraw_rt(int id) { return id == MODEL_LG1D ? 6 : id == MODEL_SV1
 SMC_HD double bits2d(uint64_t b) { return __builtin_bit_cast(double, b); }
 SMC_HD uint64_t d2bits(double d) { return __builtin_bit_cast(uint64_t, d); }
 SMC_HD double pow2i(int k) { return bits2d((uint64_t)(k + 1023) << 52); }  // 2^k, k in [-1022,1023]
+// v * 2^k for a result in the normal range: the same bits as v * pow2i(k) (an exact scaling either way); one v_ldexp_f64
+// on the device instead of building the power of two and multiplying
+SMC_HD double scale2(double v, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ldexp(v, k);
+#else
+    return v * pow2i(k);
+#endif
+}
 SMC_HD double inf() { return bits2d(0x7ff0000000000000ULL); }
 
 // round to nearest even: signed |v| < 2^51 ; non-negative of any size
@@ -150,7 +159,7 @@ SMC_HD double sp_exp(double x) {
     if (x > 709.0) return inf();
     double k;
     const double p = sp_exp_parts(x, k);
-    return p * pow2i((int)k);
+    return scale2(p, (int)k);        // x > -708: the result is a normal number
 }
 
 // a log-weight takes part in the normalisation iff it is a number of sane magnitude
