@@ -7,6 +7,9 @@ Sources of truth:
                 no toolchain; see DESIGN.md "Oracle"), so there are no reference-run outputs.
   * filter_*  : outputs of the CPU oracle (oracle/smc_oracle.c) on small seeded cases; the GPU
                 box re-derives them and the HIP path must reproduce them bit for bit.
+  * sampler_* : the PMMH pieces (proposal, accept uniform, prior log densities) of the oracle, and whole small sampler
+                runs (density_tempered, online SMC^2) of the host mirror over the oracle backend with the device-style
+                rejuvenation; the HIP backend must reproduce theta / logZ / ladder bit for bit.
 Run:  python tests/golden/make_golden.py      (from the repo root)
 """
 import json
@@ -85,7 +88,54 @@ def main():
     np.savez_compressed(os.path.join(OUT, "filter_vectors.npz"), **arrs)
     with open(os.path.join(OUT, "filter_vectors.json"), "w") as f:
         json.dump(meta, f, indent=1)
+    sampler_vectors()
     print("wrote", sorted(os.listdir(OUT)))
+
+
+def hexes(a):
+    return [float(v).hex() for v in np.asarray(a, dtype=np.float64).ravel()]
+
+
+def sampler_vectors():
+    import io
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import sequential_monte_carlo_amd as smc
+    from oracle_backend import OracleBackend
+    out = {}
+    # ---- PMMH pieces (rejuvenate!, smc_samplers.jl:114-129) ----
+    rng = np.random.default_rng(7)
+    A = rng.normal(size=(4, 4))
+    chol = np.linalg.cholesky(A @ A.T + 0.2 * np.eye(4))
+    theta = rng.normal(size=4)
+    out["pmmh"] = dict(seed=987654321, stream=41, chol=hexes(chol), theta=hexes(theta), scale=1.5,
+                       proposals={str(c): hexes(ob.pmmh_propose(987654321, 41, c, theta, chol, 1.5)) for c in (0, 1, 2)},
+                       log_uniform={str(c): float(ob.pmmh_log_uniform(987654321, 41, c)).hex() for c in (0, 1, 2)})
+    pri = {"uniform": (1, [0.0, 2.0, 0, 0, 0]), "normal": (2, [3.0, 2.0, 0, 0, 0]),
+           "truncnormal": (3, [0.0, 1.0, -1.0, 1.0, float(np.log(0.6826894921370859))]), "lognormal": (4, [0.0, 1.0, 0, 0, 0])}
+    xs = [-1.5, -0.3, 0.0, 0.4, 1.0, 1.7, 2.0, 2.5]
+    out["prior_logpdf"] = {k: dict(family=f, par=par, x=xs, logpdf=hexes([ob.prior_logpdf(f, par, x) for x in xs])) for k, (f, par) in pri.items()}
+    # ---- whole sampler runs over the oracle backend (ThetaMap path) ----
+    LGd = dict(A=0.5, B=1.0, Q=0.9, R=0.8)
+    prior = smc.product_distribution([smc.TruncatedNormal(0, 1, -1, 1), smc.LogNormal(), smc.LogNormal()])
+    tmap = smc.ThetaMap(1, [0, -1, 1, 2, -1, -1], [0.0, 1.0, 0.0, 0.0, 0.0, 1.0])
+
+    def mod(th):
+        return smc.UnivariateLinearGaussian(A=th[0], B=1.0, Q=th[1], R=th[2])
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LGd), 16, seed=1998)
+    s = smc.SMC(128, 16, mod, prior, 2, 0.5, seed=21, backend=OracleBackend(), theta_map=tmap)
+    buf = io.StringIO()
+    stages = smc.density_tempered(s, y, verbose=True, out=buf)
+    out["density_tempered_lg"] = dict(N=128, M=16, T=16, chain=2, seed=21, text=buf.getvalue(), theta=hexes(s.theta), logZ=hexes(s.logZ),
+                                      xi=hexes([st[0] for st in stages]), psteps=int(s.psteps), psteps_skipped=int(s.psteps_skipped))
+    s = smc.SMC(128, 16, mod, prior, 2, 0.6, seed=22, backend=OracleBackend(), theta_map=tmap)
+    buf = io.StringIO()
+    smc.smc2(s, y)
+    smc.smc2_run(s, y, 2, 16, window=4, verbose=True, out=buf)
+    x, w, _ = s._main.state()
+    out["smc2_lg"] = dict(N=128, M=16, T=16, chain=2, seed=22, ess_threshold=0.6, window=4, text=buf.getvalue(), theta=hexes(s.theta),
+                          logZ=hexes(s.logZ), omega=hexes(s.omega), x_sum=float(np.sum(x)).hex(), w_head=hexes(w[:, :4]), psteps=int(s.psteps))
+    with open(os.path.join(OUT, "sampler_vectors.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":

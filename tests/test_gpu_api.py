@@ -492,3 +492,13 @@ def test_filtered_summaries_on_gpu_equal_oracle_backend():
     (qh, vh), th = out[0]
     (qo, vo), to = out[1]
     assert np.array_equal(bits(qh), bits(qo)) and vh == pytest.approx(vo, rel=1e-10) and th == pytest.approx(to, rel=1e-10)
+
+
+def test_golden_sampler_vectors_on_gpu():
+    """tests/golden/sampler_vectors.json (whole sampler runs generated from the oracle backend, committed): the HIP backend
+    reproduces theta, logZ, omega, the ladder, the log text and the particle-step counts bit for bit - no oracle involved."""
+    from test_samplers_cpu import _golden_sampler_runs
+    g, out = _golden_sampler_runs(smc.smc_samplers.HipBackend)
+    for case in ("density_tempered_lg", "smc2_lg"):
+        for k, v in out[case].items():
+            assert g[case][k] == v, (case, k)

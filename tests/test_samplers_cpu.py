@@ -299,3 +299,45 @@ def test_filtered_summaries_and_trend():
         ref.append([x[0, m][o][min(np.searchsorted(cw, pp, side="right"), x.shape[2] - 1)] for pp in (0.25, 0.5, 0.75)])
     assert np.allclose(q, om @ np.array(ref), atol=0.05)
     assert smc.estimated_trend(s) == pytest.approx(float(om @ (1.0 * means)), rel=1e-9)      # B = 1 in lg_mod
+
+
+def _golden_sampler_runs(backend_factory):
+    """re-run the two committed sampler cases (tests/golden/sampler_vectors.json) on a backend -> dict like the fixture"""
+    import json
+    from conftest import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "sampler_vectors.json")))
+    hx = lambda a: [float(v).hex() for v in np.asarray(a, dtype=np.float64).ravel()]
+    out = {}
+    c = g["density_tempered_lg"]
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), c["T"], seed=1998)
+    s = smc.SMC(c["N"], c["M"], lg_mod, lg_prior(), c["chain"], 0.5, seed=c["seed"], backend=backend_factory(), theta_map=LG_TMAP)
+    buf = io.StringIO()
+    stages = smc.density_tempered(s, y, verbose=True, out=buf)
+    out["density_tempered_lg"] = dict(text=buf.getvalue(), theta=hx(s.theta), logZ=hx(s.logZ), xi=hx([st[0] for st in stages]),
+                                      psteps=int(s.psteps), psteps_skipped=int(s.psteps_skipped))
+    c = g["smc2_lg"]
+    s = smc.SMC(c["N"], c["M"], lg_mod, lg_prior(), c["chain"], c["ess_threshold"], seed=c["seed"], backend=backend_factory(), theta_map=LG_TMAP)
+    buf = io.StringIO()
+    smc.smc2(s, y)
+    smc.smc2_run(s, y, 2, c["T"], window=c["window"], verbose=True, out=buf)
+    x, w, _ = s._main.state()
+    out["smc2_lg"] = dict(text=buf.getvalue(), theta=hx(s.theta), logZ=hx(s.logZ), omega=hx(s.omega), x_sum=float(np.sum(x)).hex(),
+                          w_head=hx(w[:, :4]), psteps=int(s.psteps))
+    return g, out
+
+
+def test_golden_sampler_vectors_oracle_backend(ob):
+    """The committed sampler fixtures (PMMH pieces and whole runs, generated by tests/golden/make_golden.py from the
+    oracle): the oracle still produces them (drift detector); the GPU suite checks the HIP backend against the same file."""
+    g, out = _golden_sampler_runs(OracleBackend)
+    for case in ("density_tempered_lg", "smc2_lg"):
+        for k, v in out[case].items():
+            assert g[case][k] == v, (case, k)
+    p = g["pmmh"]
+    chol = np.array([float.fromhex(v) for v in p["chol"]]).reshape(4, 4)
+    theta = np.array([float.fromhex(v) for v in p["theta"]])
+    for c in ("0", "1", "2"):
+        assert [float(v).hex() for v in ob.pmmh_propose(p["seed"], p["stream"], int(c), theta, chol, p["scale"])] == p["proposals"][c]
+        assert float(ob.pmmh_log_uniform(p["seed"], p["stream"], int(c))).hex() == p["log_uniform"][c]
+    for k, q in g["prior_logpdf"].items():
+        assert [float(ob.prior_logpdf(q["family"], q["par"], x)).hex() for x in q["x"]] == q["logpdf"], k
