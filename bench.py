@@ -75,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="sampler workloads: weak = 512 parameter particles per GPU; strong = --n-theta in total")
     ap.add_argument("--n-theta", type=int, default=4096, help="total parameter particles of a strong-scaling sampler run")
-    ap.add_argument("--window", type=int, default=8, help="smc2: propagation steps per device call (smc2_run); 1 = one smc2! per call")
+    ap.add_argument("--window", type=int, default=16, help="smc2: propagation steps per device call (smc2_run); 1 = one smc2! per call")
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the strong-scaling sampler runs appended to a filter workload's line")

@@ -251,7 +251,11 @@ def estimated_trend(smc):
 def resample_(smc):
     """resample!(smc)   smc_samplers.jl:74-84 -- value-copy semantics."""
     w = smc.omega / smc.omega.sum()
-    a = smc.rng.choice(smc.M, size=smc.M, replace=True, p=w)     # iid multinomial, unsorted
+    a = smc.rng.choice(smc.M, size=smc.M, replace=True, p=w)     # iid multinomial (sample(1:M, Weights(w), M))
+    # The order of the resampled population carries no information (the reference's `sample` returns it unsorted); taken
+    # in ascending order slot m inherits from an ancestor close to m, so with theta sharded over GPUs most of the filter
+    # copies of the online sampler stay on their rank and only the drift of the offspring counts crosses the links.
+    a = np.sort(a)
     smc.theta = smc.theta[a].copy()
     smc.omega = smc.omega[a].copy()
     smc.logZ = smc.logZ[a].copy()
@@ -436,7 +440,7 @@ def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
     return _step_only(smc, y, t, verbose, out)
 
 
-def smc2_run(smc, y, t_from, t_to, window=8, verbose=True, out=sys.stdout):
+def smc2_run(smc, y, t_from, t_to, window=16, verbose=True, out=sys.stdout):
     """for t in t_from:t_to  smc²!(smc, y, t)  end   (the online loop of smc_samplers.jl:308-340 / README.md:93-101),
     with the same results bit for bit, but up to `window` propagation steps per device call: between two
     resample-move decisions the inner filters only need y[t], so a window of steps runs in ONE launch with the particle
