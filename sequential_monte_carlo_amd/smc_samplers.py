@@ -102,7 +102,7 @@ class HipBackend:
         -> (theta, logZ, accepted, filters_run)"""
         h = self._handle("prop", tmap.model_id, theta.shape[0], N, int(filter_seeds[0]))
         h.set_streams(streams)
-        cfg = (id(tmap), id(prior_spec))
+        cfg = (tmap.raw_from.tobytes(), tmap.raw_const.tobytes(), np.asarray(prior_spec[0]).tobytes(), np.asarray(prior_spec[1]).tobytes())   # by content
         if getattr(h, "_pmmh_cfg", None) != cfg:
             h.pmmh_configure(prior_spec[0], prior_spec[1], tmap.raw_from, tmap.raw_const)
             h._pmmh_cfg = cfg
