@@ -443,6 +443,7 @@ static int emit_if_needed(smc_handle h) {
 extern "C" int smc_init(smc_handle h, double y1, double* logmu) {
     if (!h) return fail(SMC_EINVAL, "smc_init: NULL handle");
     if (!h->have_params) return fail(SMC_ESTATE, "smc_init: smc_set_params has not been called");
+    h->win_k = 0;   // an uncommitted window is dropped
     HIPCHK(hipSetDevice(h->device));
     h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -514,6 +515,7 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     if (!h || !y) return fail(SMC_EINVAL, "smc_log_likelihood: NULL argument");
     if (T <= 0) return fail(SMC_EINVAL, "smc_log_likelihood: T must be positive");
     if (!h->have_params) return fail(SMC_ESTATE, "smc_log_likelihood: smc_set_params has not been called");
+    h->win_k = 0;   // an uncommitted window is dropped
     HIPCHK(hipSetDevice(h->device));
     int rc = ensure_y(h, T);
     if (rc) return rc;
@@ -673,7 +675,9 @@ extern "C" int smc_pmmh_rejuvenate(smc_handle h, smc_handle main, const double* 
         if (main->model != h->model || a.n != b.n || a.seg != b.seg || a.ntheta != b.ntheta || main->device != h->device)
             return fail(SMC_EINVAL, "smc_pmmh_rejuvenate: handles differ in model, geometry or device");
         if (!main->inited) return fail(SMC_ESTATE, "smc_pmmh_rejuvenate: main filters not initialised");
+        main->win_k = 0;
     }
+    h->win_k = 0;
     HIPCHK(hipSetDevice(h->device));
     const PmmhSpec& sp = h->pm_spec;
     const int nt = h->v.ntheta, d = sp.d;
@@ -849,6 +853,7 @@ extern "C" int smc_get_logZ(smc_handle h, double* logZ, double* ess) {
 extern "C" int smc_permute(smc_handle h, const int32_t* a) {
     if (!h || !a) return fail(SMC_EINVAL, "smc_permute: NULL argument");
     if (!h->inited) return fail(SMC_ESTATE, "smc_permute: filter not initialised");
+    h->win_k = 0;
     for (int m = 0; m < h->v.ntheta; ++m)
         if (a[m] < 0 || a[m] >= h->v.ntheta) return fail(SMC_EINVAL, "smc_permute: index out of range");
     HIPCHK(hipSetDevice(h->device));
@@ -873,6 +878,7 @@ extern "C" int smc_copy_from(smc_handle dst, smc_handle src, const uint8_t* mask
     if (!dst || !src || !mask) return fail(SMC_EINVAL, "smc_copy_from: NULL argument");
     if (dst == src) return fail(SMC_EINVAL, "smc_copy_from: dst and src are the same handle");
     if (!dst->inited || !src->inited) return fail(SMC_ESTATE, "smc_copy_from: filter not initialised");
+    dst->win_k = 0;
     const FilterView &a = dst->v, &b = src->v;
     if (dst->model != src->model || a.n != b.n || a.seg != b.seg || a.ntheta != b.ntheta || dst->device != src->device)
         return fail(SMC_EINVAL, "smc_copy_from: handles differ in model, geometry or device");
@@ -901,6 +907,7 @@ extern "C" int smc_slot_bytes(smc_handle h, int64_t* bytes) {
 static int pack_unpack(smc_handle h, const int32_t* idx, int64_t k, void* buf, bool pack) {
     if (!h || k < 0 || (k > 0 && (!idx || !buf))) return fail(SMC_EINVAL, "smc_pack/unpack_slots: bad argument");
     if (!h->inited) return fail(SMC_ESTATE, "smc_pack/unpack_slots: filter not initialised");
+    if (!pack) h->win_k = 0;
     if (k == 0) return SMC_OK;
     for (int64_t i = 0; i < k; ++i)
         if (idx[i] < 0 || idx[i] >= h->v.ntheta) return fail(SMC_EINVAL, "smc_pack/unpack_slots: index out of range");
