@@ -168,6 +168,11 @@ int smc_comm_all_gather(smc_comm c, const double* local /*[n]*/, int64_t n, doub
 int smc_outer_reweight(smc_comm c, const double* logw_local /*[n_local]*/, int64_t n_local, double* logw_all,
                        double* w_all /*[n_local*world]*/, double* logmu, double* ess);
 int smc_comm_exchange_slots(smc_comm c, smc_handle h, const int32_t* a /*[M]*/, int64_t M);
+/* the plan smc_comm_exchange_slots follows, as pure host arithmetic (no GPU; tested on CPU against the Python twin):
+ * send_idx [<= M] local slots to pack, grouped by destination rank (send_cnt [world], *n_send in total); dest_idx [M/world]
+ * local slots to unpack into, grouped by source rank (recv_cnt [world]) */
+int smc_comm_plan_exchange(const int32_t* a /*[M]*/, int64_t M, int rank, int world, int32_t* send_idx, int64_t* send_cnt /*[world]*/,
+                           int64_t* n_send, int32_t* dest_idx, int64_t* recv_cnt /*[world]*/);
 
 /* raw fixed-point weight state (tests): C [n_theta][nseg*seg], m/S/S2hi/S2lo [n_theta][nseg] */
 int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo);

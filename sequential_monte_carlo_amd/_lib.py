@@ -24,7 +24,7 @@ EXPORTS = [
     "smc_set_skip", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_host_pmmh_propose", "smc_host_pmmh_log_uniform",
     "smc_host_prior_logpdf", "smc_step_window", "smc_step_commit",
     "smc_comm_unique_id", "smc_comm_create", "smc_comm_destroy", "smc_comm_rank", "smc_comm_all_gather", "smc_outer_reweight",
-    "smc_comm_exchange_slots", "smc_host_reweight", "smc_host_outer_steps",
+    "smc_comm_exchange_slots", "smc_host_reweight", "smc_host_outer_steps", "smc_comm_plan_exchange",
 ]
 COMM_ID_BYTES = 128
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
@@ -134,6 +134,8 @@ def lib():
     L.smc_comm_all_gather.argtypes = [h, _dp, C.c_int64, _dp]
     L.smc_outer_reweight.argtypes = [h, _dp, C.c_int64, _dp, _dp, _dp, _dp]
     L.smc_comm_exchange_slots.argtypes = [h, h, _i32p, C.c_int64]
+    L.smc_comm_plan_exchange.argtypes = [_i32p, C.c_int64, C.c_int, C.c_int, _i32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _i32p,
+                                         C.POINTER(C.c_int64)]
     L.smc_last_error.restype = C.c_char_p
     L.smc_version.restype = C.c_char_p
     _lib = L

@@ -176,6 +176,30 @@ extern "C" int smc_outer_reweight(smc_comm c, const double* logw_local, int64_t 
     return smc_normalize(all, n, w_all, logmu, ess, c->device);   // the same integer-sum normalize on every rank
 }
 
+// Who sends which slot to whom (pure host arithmetic, exported so that it can be tested without GPUs).  What rank `rank`
+// sends to rank r: its own slots among the ancestors of r's slots, in r's slot order (send_idx: LOCAL indices, grouped by
+// destination, send_cnt[r] of them); what it receives from rank s: one packed slot for every local slot whose ancestor lives
+// on s, in local slot order (dest_idx: LOCAL indices grouped by source, recv_cnt[s] of them, M/world in total).
+extern "C" int smc_comm_plan_exchange(const int32_t* a, int64_t M, int rank, int world, int32_t* send_idx, int64_t* send_cnt,
+                                      int64_t* n_send, int32_t* dest_idx, int64_t* recv_cnt) {
+    if (!a || !send_idx || !send_cnt || !n_send || !dest_idx || !recv_cnt || M <= 0 || world < 1 || rank < 0 || rank >= world || M % world)
+        return smc_set_error_(SMC_EINVAL, "smc_comm_plan_exchange: bad argument");
+    const int64_t per = M / world, lo = rank * per;
+    int64_t ns = 0, nr = 0;
+    for (int r = 0; r < world; ++r) {
+        send_cnt[r] = 0;
+        for (int64_t m = r * per; m < (r + 1) * per; ++m)
+            if (a[m] / per == rank) { send_idx[ns++] = (int32_t)(a[m] - lo); ++send_cnt[r]; }
+    }
+    for (int s = 0; s < world; ++s) {
+        recv_cnt[s] = 0;
+        for (int64_t m = 0; m < per; ++m)
+            if (a[lo + m] / per == s) { dest_idx[nr++] = (int32_t)m; ++recv_cnt[s]; }
+    }
+    *n_send = ns;
+    return SMC_OK;
+}
+
 // resample!(smc) with the filters of `h` sharded over the ranks: a[m] (m = 0..M-1, GLOBAL indices, the same vector on
 // every rank) is the ancestor of global slot m; rank r holds the slots [r M/world, (r+1) M/world).  Value copies.
 extern "C" int smc_comm_exchange_slots(smc_comm c, smc_handle h, const int32_t* a, int64_t M) {
@@ -188,16 +212,12 @@ extern "C" int smc_comm_exchange_slots(smc_comm c, smc_handle h, const int32_t* 
     int64_t sb = 0;
     int rc = smc_slot_bytes(h, &sb);
     if (rc) return rc;
-    // what this rank sends to rank r: its own slots among the ancestors of r's slots (in r's slot order); what it receives
-    // from rank s: one packed slot for every local slot whose ancestor lives on s (in local slot order)
-    std::vector<int32_t> send_idx, dest_idx;
+    std::vector<int32_t> send_idx((size_t)M), dest_idx((size_t)per);
     std::vector<int64_t> send_cnt((size_t)W, 0), recv_cnt((size_t)W, 0);
-    for (int r = 0; r < W; ++r)
-        for (int64_t m = r * per; m < (r + 1) * per; ++m)
-            if (a[m] / per == c->rank) { send_idx.push_back((int32_t)(a[m] - lo)); ++send_cnt[(size_t)r]; }
-    for (int s = 0; s < W; ++s)
-        for (int64_t m = 0; m < per; ++m)
-            if (a[lo + m] / per == s) { dest_idx.push_back((int32_t)m); ++recv_cnt[(size_t)s]; }
+    int64_t n_send = 0;
+    rc = smc_comm_plan_exchange(a, M, c->rank, W, send_idx.data(), send_cnt.data(), &n_send, dest_idx.data(), recv_cnt.data());
+    if (rc) return rc;
+    send_idx.resize((size_t)n_send);
     const size_t ns = send_idx.size(), nr = dest_idx.size();   // nr == per
     const size_t need = (ns > nr ? ns : nr) * (size_t)sb;
     if (need > c->xcap) {

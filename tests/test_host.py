@@ -226,3 +226,49 @@ def test_host_reweight_is_normalize(L):
     om2, lz2, ess2, j2 = L.host_outer_steps(omega0, logZ0, lik, ess_min=thr + 1e-9)
     first = int(np.argmax(ess < thr + 1e-9)) + 1
     assert j2 == first and np.array_equal(ess2, ess[:first]) and np.array_equal(bits(lz2), bits(logZ0 + lik[:first].sum(axis=0))) or j2 == first
+
+
+def test_exchange_plan_c_equals_python_and_is_consistent(L):
+    """smc_comm_plan_exchange (the host arithmetic of the C-level all-to-all of filter slots) for worlds of 1..8 ranks:
+    identical to the plan distributed.ThetaComm.exchange_slots derives, every rank's sends match the other ranks' receives,
+    and replaying the plan on plain arrays performs resample!(smc) (slot m <- slot a[m], smc_samplers.jl:74-84)."""
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    lib = L.lib()
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    for world in (1, 2, 3, 4, 8):
+        per = 6
+        M = per * world
+        for trial in range(4):
+            a = np.sort(rng.integers(0, M, M)).astype(np.int32) if trial % 2 else rng.integers(0, M, M).astype(np.int32)
+            plans = []
+            for rank in range(world):
+                send_idx, dest_idx = np.zeros(M, np.int32), np.zeros(per, np.int32)
+                send_cnt, recv_cnt, ns = np.zeros(world, np.int64), np.zeros(world, np.int64), C.c_int64()
+                assert lib.smc_comm_plan_exchange(a.ctypes.data_as(i32p), M, rank, world, send_idx.ctypes.data_as(i32p),
+                                                  send_cnt.ctypes.data_as(i64p), C.byref(ns), dest_idx.ctypes.data_as(i32p),
+                                                  recv_cnt.ctypes.data_as(i64p)) == 0
+                send_idx = send_idx[:ns.value]
+                # the Python twin (distributed.py)
+                lo = rank * per
+                p_send = [a[r * per:(r + 1) * per][(a[r * per:(r + 1) * per] // per) == rank] - lo for r in range(world)]
+                owners = a[lo:lo + per] // per
+                p_dest = np.concatenate([np.nonzero(owners == s)[0] for s in range(world)])
+                assert np.array_equal(send_idx, np.concatenate(p_send)) and [len(q) for q in p_send] == list(send_cnt)
+                assert np.array_equal(dest_idx, p_dest) and [int((owners == s).sum()) for s in range(world)] == list(recv_cnt)
+                plans.append((send_idx, send_cnt, dest_idx, recv_cnt))
+            # replay on plain data: slot value = global slot id
+            data = [np.arange(r * per, (r + 1) * per) for r in range(world)]
+            new = [d.copy() for d in data]
+            for r in range(world):                       # receiver
+                _, _, dest_idx, recv_cnt = plans[r]
+                off = 0
+                for s in range(world):                   # sender
+                    send_idx, send_cnt, _, _ = plans[s]
+                    start = int(send_cnt[:r].sum())
+                    chunk = data[s][send_idx[start:start + int(send_cnt[r])]]
+                    assert len(chunk) == recv_cnt[s]
+                    new[r][dest_idx[off:off + len(chunk)]] = chunk
+                    off += len(chunk)
+            assert np.array_equal(np.concatenate(new), a)
+    assert lib.smc_comm_plan_exchange(None, 4, 0, 2, None, None, None, None, None) == -1
