@@ -206,7 +206,7 @@ extern "C" int smc_comm_exchange_slots(smc_comm c, smc_handle h, const int32_t* 
     if (!c || !h || !a || M <= 0 || M % c->world) return smc_set_error_(SMC_EINVAL, "smc_comm_exchange_slots: bad argument");
     HIPC(hipSetDevice(c->device));
     const int W = c->world;
-    const int64_t per = M / W, lo = c->rank * per;
+    const int64_t per = M / W;
     for (int64_t m = 0; m < M; ++m)
         if (a[m] < 0 || a[m] >= M) return smc_set_error_(SMC_EINVAL, "smc_comm_exchange_slots: ancestor out of range");
     int64_t sb = 0;
