@@ -431,6 +431,76 @@ __global__ __launch_bounds__(THREADS) void k_normalize(const double* logw, int64
     }
 }
 
+// The same normalize() for long vectors (a whole particle cloud's log-weights): three grid-wide passes.  Every
+// cross-workgroup combination is an integer operation (max of the integer exponents, sums of the fixed-point weights, sums
+// of the three 32-bit limbs of their squares), so the order the workgroups arrive in cannot change a bit: the results are
+// those of the one-workgroup kernel above.  acc: [0] sum q  [1..3] sums of the limbs of q^2; kmax_i: exponent maximum.
+constexpr int NORM_DEAD = (int)0x80000000;
+__device__ __forceinline__ uint64_t norm_q(double l, int kmax_i, int K) {
+    if (!lw_alive(l) || kmax_i == NORM_DEAD) return 0;
+    double k;
+    const double p = sp_exp_parts(l, k);
+    return fix_weight(p, k - (double)kmax_i, K);
+}
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_normalize_max(const double* logw, int64_t n, int* kmax_i) {
+    __shared__ int red[THREADS / WAVE];
+    int km = NORM_DEAD;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const double l = logw[i];
+        if (lw_alive(l)) { double k; (void)sp_exp_parts(l, k); const int ki = (int)k; km = ki > km ? ki : km; }
+    }
+    km = block_max_i32<THREADS>(km, red);
+    if (threadIdx.x == 0 && km != NORM_DEAD) atomicMax(kmax_i, km);
+}
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_normalize_sum(const double* logw, int64_t n, int K, const int* kmax_i,
+                                                          unsigned long long* acc) {
+    constexpr int NW = THREADS / WAVE;
+    __shared__ uint64_t part[4][NW];
+    const int km = *kmax_i, lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    uint64_t s[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const uint64_t q = norm_q(logw[i], km, K);
+        const U128 q2 = sq128(q);
+        s[0] += q;
+        s[1] += q2.lo & 0xffffffffULL;
+        s[2] += q2.lo >> 32;
+        s[3] += q2.hi;                     // q < 2^48: q^2 < 2^96, the top limb is below 2^32
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t t = wave_sum(s[j]);
+        if (lane == 0) part[j][wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        uint64_t t = 0;
+        for (int w = 0; w < NW; ++w) t += part[threadIdx.x][w];
+        if (t) atomicAdd(&acc[threadIdx.x], (unsigned long long)t);
+    }
+}
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_normalize_write(const double* logw, int64_t n, int K, const int* kmax_i,
+                                                            const unsigned long long* acc, double* w, double* out2) {
+    const int km = *kmax_i;
+    const uint64_t St = acc[0];
+    const double Sd = (double)St;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) {
+        const uint64_t q = norm_q(logw[i], km, K);
+        w[i] = St ? (double)q / Sd : 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // sum q^2 = l0 + l1 2^32 + l2 2^64 as a 128-bit integer
+        const uint64_t l0 = acc[1], l1 = acc[2], l2 = acc[3];
+        const uint64_t lo = l0 + (l1 << 32);
+        const uint64_t hi = l2 + (l1 >> 32) + (lo < l0 ? 1u : 0u);
+        const double kmax = km == NORM_DEAD ? -inf() : (double)km;
+        out2[0] = St ? fma(kmax, LN2_HI, fma(kmax, LN2_LO, sp_log(Sd * pow2i(-K)))) - sp_log((double)n) : -inf();
+        out2[1] = St ? (Sd * Sd) / u128_to_double(hi, lo) : 0.0;
+    }
+}
+
 // q_i = rint(w_i / wmax * 2^K) ; C = inclusive scan (single workgroup, chunked)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_resample_cdf(const double* w, int64_t n, int K, uint64_t* C, int* status) {

@@ -1016,9 +1016,34 @@ extern "C" int smc_normalize(const double* logw, int64_t n, double* w, double* l
     HIPCHK(d_w.alloc((size_t)n * 8));
     HIPCHK(d_o.alloc(16));
     HIPCHK(hipMemcpyAsync(d_in.p, logw, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    // one workgroup: the outer reweight works on n_theta-vectors (a few thousand entries)
-    hipLaunchKernelGGL((k_normalize<1024>), dim3(1), dim3(1024), 0, st, d_in.as<double>(), n, fix_bits_for(n), d_w.as<double>(), d_o.as<double>());
-    HIPCHK(hipGetLastError());
+    if (n <= 16384) {
+        // one workgroup: the outer reweight works on n_theta-vectors (a few thousand entries)
+        hipLaunchKernelGGL((k_normalize<1024>), dim3(1), dim3(1024), 0, st, d_in.as<double>(), n, fix_bits_for(n), d_w.as<double>(), d_o.as<double>());
+        HIPCHK(hipGetLastError());
+    } else {
+        // a whole cloud's log-weights: three grid-wide passes, every cross-workgroup combination an integer one (same bits)
+        DevBuf d_acc;
+        HIPCHK(d_acc.alloc(5 * 8));
+        unsigned long long* acc = d_acc.as<unsigned long long>();
+        int* kmax_i = reinterpret_cast<int*>(acc + 4);
+        HIPCHK(hipMemsetAsync(acc, 0, 32, st));
+        HIPCHK(hipMemsetD32Async(kmax_i, NORM_DEAD, 1, st));
+        int64_t nb = (n + 4 * 256 - 1) / (4 * 256);
+        nb = nb > 2048 ? 2048 : nb;
+        const int K = fix_bits_for(n);
+        hipLaunchKernelGGL((k_normalize_max<256>), dim3((unsigned)nb), dim3(256), 0, st, d_in.as<double>(), n, kmax_i);
+        hipLaunchKernelGGL((k_normalize_sum<256>), dim3((unsigned)nb), dim3(256), 0, st, d_in.as<double>(), n, K, kmax_i, acc);
+        hipLaunchKernelGGL((k_normalize_write<256>), dim3((unsigned)nb), dim3(256), 0, st, d_in.as<double>(), n, K, kmax_i, acc,
+                           d_w.as<double>(), d_o.as<double>());
+        HIPCHK(hipGetLastError());
+        double o[2];
+        HIPCHK(hipMemcpyAsync(w, d_w.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(o, d_o.p, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));       // (d_acc lives until here)
+        if (logmu) *logmu = o[0];
+        if (ess) *ess = o[1];
+        return SMC_OK;
+    }
     double o[2];
     HIPCHK(hipMemcpyAsync(w, d_w.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(o, d_o.p, 16, hipMemcpyDeviceToHost, st));

@@ -161,7 +161,7 @@ def test_step_api_matches_whole_series(L, ob):
 
 def test_standalone_normalize_resample(L, ob):
     rng = np.random.default_rng(11)
-    for n in (1, 2, 63, 512, 4096, 100000):
+    for n in (1, 2, 63, 512, 4096, 16384, 16385, 100000, 1 << 20):      # > 16384: the three-pass grid-wide kernels
         logw = rng.normal(size=n) * 5 - 100
         if n > 10:
             logw[3] = -np.inf
@@ -171,6 +171,10 @@ def test_standalone_normalize_resample(L, ob):
         assert same(w, ow) and same([lmu, ess], [olmu, oess])
         a = L.resample(ow, 3 * n + 1, seed=4, stream=2, t=n % 100)
         assert np.array_equal(a, ob.resample(ow, 3 * n + 1, seed=4, stream=2, t=n % 100))
+    dead = np.full(20000, -np.inf)                                 # no live entry at all, long vector
+    lmu, w, ess = L.normalize(dead)
+    olmu, ow, oess = ob.normalize(dead)
+    assert same(w, ow) and same([lmu, ess], [olmu, oess])
     with pytest.raises(L.SmcError):
         L.resample(np.zeros(8))
 
