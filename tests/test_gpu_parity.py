@@ -715,3 +715,27 @@ def test_launch_geometry_knobs_do_not_change_results(L, ob):
     finally:
         os.environ.pop("SMC_NP", None)
         os.environ.pop("SMC_RES_NP", None)
+
+
+def test_sv_full_size_against_grid_filter(L):
+    """C3's model at Nx = 2^20 against the deterministic grid filter (oracle/grid_filter.py; the known answer for the
+    non-Gaussian model, as the Kalman likelihood is for C2): sd(logZ) at this size is ~0.01-0.02, 0.08 is > 4 sd."""
+    from oracle import grid_filter
+    T = 200
+    _, y = L.simulate(2, SV, T, 1998)
+    g = grid_filter.sv_log_likelihood(y, *SV, n_grid=3001)
+    zs = []
+    for seed in (1, 2):
+        h = L.Handle(2, 1, 1 << 20, seed=seed)
+        h.set_params(SV)
+        zs.append(h.log_likelihood(y)[0])
+        h.close()
+    assert abs(zs[0] - g) < 0.08 and abs(zs[1] - g) < 0.08 and zs[0] != zs[1], (zs, g)
+    # and 256 batched 1024-particle filters (the LDS-resident kernel): unbiased for the same number
+    h = L.Handle(2, 256, 1024, seed=9)
+    h.set_params(np.tile(SV, (256, 1)))
+    z = h.log_likelihood(y[:60])
+    g60 = grid_filter.sv_log_likelihood(y[:60], *SV, n_grid=3001)
+    r = np.exp(z - g60)
+    assert abs(r.mean() - 1.0) < 4.5 * r.std(ddof=1) / 16 and abs(z.mean() + 0.5 * z.var(ddof=1) - g60) < 4.5 * z.std(ddof=1) / 16
+    h.close()

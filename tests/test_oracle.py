@@ -257,3 +257,25 @@ def test_oracle_kalman_matches_numpy_restatement(ob):
             x, S, z = ob.kalman_log_likelihood(raw, y, pf)
             rx, rS, rz = kalman.log_likelihood(y, *raw[:4], x0=raw[4], sigma0=raw[5], predict_first=pf)
             assert z == pytest.approx(rz, rel=1e-12) and x == pytest.approx(rx, rel=1e-11) and S == pytest.approx(rS, rel=1e-11)
+
+
+def test_sv_particle_filter_pinned_by_grid_filter(ob):
+    """The stochastic-volatility model (BASELINE configs[2]; no closed form, not in the reference's src/) against an
+    independent deterministic answer: the forward recursion on a 3001-point grid of the state (oracle/grid_filter.py).
+    The grid answer is converged (two grid sizes agree to 1e-6); the particle estimate is unbiased for it and its variance
+    falls like 1/Nx - the same two properties the Kalman likelihood pins for the linear-Gaussian model."""
+    from oracle import grid_filter
+    SV = [-1.0, 0.95, 0.25]
+    _, y = ob.simulate(ob.SV1D, SV, 60, 1998)
+    g1 = grid_filter.sv_log_likelihood(y, *SV, n_grid=3001)
+    g2 = grid_filter.sv_log_likelihood(y, *SV, n_grid=1501)
+    assert abs(g1 - g2) < 1e-6
+    K = 96
+    for seg in (0, 256):
+        z = np.array([ob.Filter(ob.SV1D, SV, 1024, seg=seg, seed=3000 + s).log_likelihood(y) for s in range(K)])
+        se = z.std(ddof=1) / np.sqrt(K)
+        assert abs(z.mean() + 0.5 * z.var(ddof=1) - g1) < 4.5 * se, (z.mean(), z.var(ddof=1), g1)
+        r = np.exp(z - g1)
+        assert abs(r.mean() - 1.0) < 4.5 * r.std(ddof=1) / np.sqrt(K)
+    z4 = np.array([ob.Filter(ob.SV1D, SV, 4096, seed=4000 + s).log_likelihood(y) for s in range(48)])
+    assert z4.var(ddof=1) < 0.6 * z.var(ddof=1) and abs(z4.mean() - g1) < 0.1
