@@ -502,3 +502,41 @@ def test_golden_sampler_vectors_on_gpu():
     for case in ("density_tempered_lg", "smc2_lg"):
         for k, v in out[case].items():
             assert g[case][k] == v, (case, k)
+
+
+class _KalmanBackend:
+    """A filter "backend" that returns the EXACT log-likelihood of the linear-Gaussian model (batched scalar Kalman filter on
+    the device, kalman_filter.jl:29-70) instead of a particle estimate: the sampler on top of it is the ideal sampler that
+    the pseudo-marginal one (particle filters inside PMMH) must agree with in distribution."""
+
+    def log_likelihood(self, models, N, y, seed, streams, key="prop", skip=None):
+        from sequential_monte_carlo_amd import _lib as L
+        mid, raw = smc.smc_samplers._rows(models)
+        out = L.kalman_log_likelihood(raw, y, predict_first=False)[:, 2]
+        if skip is not None:
+            out = np.where(np.asarray(skip, dtype=bool), -np.inf, out)
+        return out, None
+
+    def close(self):
+        pass
+
+
+def test_density_tempered_posterior_matches_exact_likelihood_sampler():
+    """density_tempered with particle filters inside (the device path) against the same sampler driven by the exact Kalman
+    likelihood: a pseudo-marginal sampler targets the same posterior, so the posterior means must agree within Monte-Carlo
+    error, and so must the tempering ladders (same data, same prior, same ESS rule)."""
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 100, seed=1998)
+    pf, kf, ladders = [], [], []
+    for seed in range(1, 7):
+        s = smc.SMC(1024, 512, lg_mod, lg_prior(), 3, 0.5, seed=seed, theta_map=LG_TMAP)
+        st = smc.density_tempered(s, y, verbose=False)
+        pf.append(smc.expected_parameters(s))
+        s.backend.close()
+        k = smc.SMC(1, 512, lg_mod, lg_prior(), 3, 0.5, seed=100 + seed, backend=_KalmanBackend())
+        sk = smc.density_tempered(k, y, verbose=False)
+        kf.append(smc.expected_parameters(k))
+        ladders.append((len(st), len(sk), st[0][0], sk[0][0]))
+    pf, kf = np.array(pf), np.array(kf)
+    se = np.sqrt(pf.var(axis=0, ddof=1) / len(pf) + kf.var(axis=0, ddof=1) / len(kf))
+    assert np.all(np.abs(pf.mean(axis=0) - kf.mean(axis=0)) < 4.5 * se + 0.02), (pf.mean(axis=0), kf.mean(axis=0), se)
+    assert all(abs(a - b) <= 1 for a, b, _, _ in ladders) and all(abs(np.log(p / q)) < 0.5 for _, _, p, q in ladders)
