@@ -540,3 +540,22 @@ def test_density_tempered_posterior_matches_exact_likelihood_sampler():
     se = np.sqrt(pf.var(axis=0, ddof=1) / len(pf) + kf.var(axis=0, ddof=1) / len(kf))
     assert np.all(np.abs(pf.mean(axis=0) - kf.mean(axis=0)) < 4.5 * se + 0.02), (pf.mean(axis=0), kf.mean(axis=0), se)
     assert all(abs(a - b) <= 1 for a, b, _, _ in ladders) and all(abs(np.log(p / q)) < 0.5 for _, _, p, q in ladders)
+
+
+def test_online_smc2_posterior_matches_density_tempered_and_exact():
+    """Online SMC^2 (smc² + smc²! for t = 2..T) ends at the same posterior p(theta | y_1:T) as density_tempered and as the
+    exact-likelihood sampler: posterior means agree within Monte-Carlo error."""
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 100, seed=1998)
+    on, kf = [], []
+    for seed in range(1, 7):
+        s = smc.SMC(1024, 512, lg_mod, lg_prior(), 3, 0.5, seed=40 + seed, theta_map=LG_TMAP)
+        smc.smc2(s, y)
+        smc.smc2_run(s, y, 2, 100, verbose=False)
+        on.append(smc.expected_parameters(s))
+        s.backend.close()
+        k = smc.SMC(1, 512, lg_mod, lg_prior(), 3, 0.5, seed=200 + seed, backend=_KalmanBackend())
+        smc.density_tempered(k, y, verbose=False)
+        kf.append(smc.expected_parameters(k))
+    on, kf = np.array(on), np.array(kf)
+    se = np.sqrt(on.var(axis=0, ddof=1) / len(on) + kf.var(axis=0, ddof=1) / len(kf))
+    assert np.all(np.abs(on.mean(axis=0) - kf.mean(axis=0)) < 4.5 * se + 0.03), (on.mean(axis=0), kf.mean(axis=0), se)
