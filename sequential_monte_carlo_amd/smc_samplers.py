@@ -1,4 +1,6 @@
-"""Host mirror of src/smc_samplers.jl: SMC, density_tempered, smc2 ("smc²"), smc2_step ("smc²!").
+"""Host mirror of src/smc_samplers.jl: SMC, density_tempered, smc2 ("smc²"), smc2_step ("smc²!"), smc2_run (the
+`for t in 2:T smc²!(smc,y,t) end` loop, several steps per device call), rejuvenate_, resample_, exchange!, and the
+summaries of plotting_utils.jl / the example script (estimated_trend, filtered_summaries).
 
 The O(n_theta) outer logic (bisection for the tempering exponent, resample!, the PMMH accept test,
 the random-walk kernel) stays on the host exactly as in the reference; every particle filter the
@@ -15,9 +17,11 @@ are batched on the GPU.  Either way a proposal outside the prior's support is ne
 
 theta sharding (multi-GPU): pass `comm=ThetaComm(...)` (distributed.py).  Every rank holds the full
 (small) theta / logZ vectors and draws the same host random numbers from the same seed, so all ranks
-take identical decisions; a rank only *filters* its own contiguous slice of theta, and the slices of
-logZ are exchanged with one all-gather per evaluation (the collective point of SURVEY 8e).
-Results do not depend on the number of ranks: filter m always uses Philox stream id m.
+take identical decisions; a rank only *filters* its own contiguous slice of theta.  Collectives: one
+all-gather of the logZ slices per batched evaluation, one all-gather of the moved (theta, logZ, accepted) slices per
+rejuvenation, one all-gather of the log-likelihood increments per window of online steps, and one all-to-all of
+filter slots per resample! of the online sampler.  Results do not depend on the number of ranks: filter m always
+uses Philox stream id m.
 """
 import math
 import sys
