@@ -85,6 +85,7 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
         __syncthreads();
     }
 
+    const bool ragged = (int)v.n != SEG;   // workgroup-uniform
     for (int t = t0; t < t0 + T; ++t) {
         const double y = v.y[t - t0];
         double xp[NQ][D];
@@ -123,11 +124,21 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
                 for (int i = 0; i < NQ; ++i) pb[i] += (val[i] <= T2[i]) ? 8 * lds_step_inc(s) : 0;
             }
             const int last_p = lds_pad((int)v.n - 1);
+            int apos[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) apos[i] = (int)(pb[i] - lds_ptr(Cs)) >> 3;   // T2 < S = C[n-1]: a position below n
+            if (S == 0 || ragged) {   // workgroup-uniform and rare: a real branch
+                asm volatile("; collapsed or ragged");
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const int own = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+                    const int ap = S ? apos[i] : lds_pad(own);   // collapsed filter: identity
+                    apos[i] = ap < last_p ? ap : last_p;         // lds_pad is increasing: the clamp to n-1 commutes with it
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                const int own = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
-                int ap = S ? (int)(pb[i] - lds_ptr(Cs)) >> 3 : lds_pad(own);   // collapsed filter: identity
-                ap = ap < last_p ? ap : last_p;   // lds_pad is increasing: the clamp to n-1 commutes with it
+                const int ap = apos[i];
                 anc[i] = ap;
 #pragma unroll
                 for (int c = 0; c < D; ++c) xp[i][c] = xs[c * SEGP + ap];
@@ -136,22 +147,52 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
 #pragma unroll
             for (int i = 0; i < NQ; ++i) anc[i] = lds_pad(2 * (tid + (i >> 1) * THREADS) + (i & 1));
         }
+        double z[NP][D][2];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int i0 = 2 * (tid + k * THREADS);
-            const uint32_t pg = (uint32_t)(i0 >> 1);
-            double z[D][2];
+            const uint32_t pg = (uint32_t)(tid + k * THREADS);
 #pragma unroll
-            for (int c = 0; c < D; ++c) box_muller(draw(v.seed, pg, stream, (uint32_t)t, SLOT_NORMAL0 + c), z[c][0], z[c][1]);
+            for (int c = 0; c < D; ++c) box_muller(draw(v.seed, pg, stream, (uint32_t)t, SLOT_NORMAL0 + c), z[k][c][0], z[k][c][1]);
+        }
+        if (t > 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                double zz[D];
+            for (int k = 0; k < NP; ++k)
 #pragma unroll
-                for (int c = 0; c < D; ++c) zz[c] = z[c][j];
-                if (t > 0) model_transition<MODEL>(prm, xp[2 * k + j], zz, xn[k][j]);
-                else model_initial<MODEL>(prm, zz, xn[k][j]);
-                lw[k][j] = (i0 + j) < v.n ? model_logobs<MODEL>(prm, xn[k][j], y) : nan_mask();
-            }
+                for (int j = 0; j < 2; ++j) {
+                    double zz[D];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) zz[c] = z[k][c][j];
+                    model_transition<MODEL>(prm, xp[2 * k + j], zz, xn[k][j]);
+                }
+        } else {
+            // a real (workgroup-uniform) branch: flattened into selects, every step of the series would also evaluate the
+            // initial distribution
+            asm volatile("; t = 0");
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    double zz[D];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) zz[c] = z[k][c][j];
+                    model_initial<MODEL>(prm, zz, xn[k][j]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lw[k][j] = model_logobs<MODEL>(prm, xn[k][j], y);
+        if (ragged) {   // n < SEG: the particles beyond n carry NaN weights and zero states (a real branch: the samplers' filters are full)
+            asm volatile("; ragged");
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if ((2 * (tid + k * THREADS) + j) >= v.n) {
+                        lw[k][j] = nan_mask();
+#pragma unroll
+                        for (int c = 0; c < D; ++c) xn[k][j][c] = 0.0;
+                    }
         }
         __syncthreads();  // every gather from xs / Cs is done
         SMC_PRIO(2);
@@ -161,8 +202,8 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
 #pragma unroll
             for (int c = 0; c < D; ++c) {
                 double2 o;
-                o.x = i0 < v.n ? xn[k][0][c] : 0.0;
-                o.y = (i0 + 1) < v.n ? xn[k][1][c] : 0.0;
+                o.x = xn[k][0][c];
+                o.y = xn[k][1][c];
                 *reinterpret_cast<double2*>(xs + c * SEGP + lds_pad(i0)) = o;
             }
         }
