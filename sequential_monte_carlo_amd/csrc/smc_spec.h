@@ -90,6 +90,15 @@ SMC_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// a ^ (b & c): one v_bitop3_b32 as well
+SMC_HD uint32_t xor_and(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x78);   // 0xF0 ^ (0xCC & 0xAA)
+#else
+    return a ^ (b & c);
+#endif
+}
+
 SMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -127,6 +136,41 @@ __device__ __forceinline__ double fma_const(double p, double r) {
 #define SMC_FMAK(p, r, c) fma_const<__builtin_bit_cast(uint64_t, (double)(c))>((p), (r))
 #else
 #define SMC_FMAK(p, r, c) fma((p), (r), (c))
+#endif
+
+// ---- division and square root without their range handling ---------------------------------
+// n / d and sqrt(x) for operands of moderate magnitude: the refinement sequences of the compiler's IEEE expansions without
+// the operand scaling (v_div_scale, v_ldexp) and the special-value fix-ups around them - inactive for these operands, so the
+// results are the same bits (the host side, and the oracle, use the correctly rounded library operations they reproduce).
+#if defined(__HIP_DEVICE_COMPILE__)
+// |d| in [2^-500, 2^500], n zero or |n / d| in [2^-500, 2^500]
+__device__ __forceinline__ double div_moderate(double n, double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    const double q = n * y;
+    const double r = fma(-d, q, n);
+    return fma(r, y, q);
+}
+// x = -0.0 or x in [2^-500, 2^500]   (sqrt(-0.0) = -0.0: the refinement turns it into NaN, which the maximum drops)
+__device__ __forceinline__ double sqrt_moderate_or_negzero(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    double d = fma(-g, g, x);
+    h = fma(h, r, h);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return __builtin_fmax(g, -0.0);
+}
+#else
+inline double div_moderate(double n, double d) { return n / d; }
+inline double sqrt_moderate_or_negzero(double x) { return sqrt(x); }
 #endif
 
 // ---- exp / log / sincos ----------------------------------------------------------------
@@ -184,7 +228,7 @@ SMC_HD double sp_log_normal(double x, int e0) {
     double m = bits2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
     if (m > SQRT2) { m *= 0.5; e += 1; }
     const double f = m - 1.0;
-    const double s = f / (2.0 + f);
+    const double s = div_moderate(f, 2.0 + f);   // f in [-0.2929, 0.4143]: zero or of magnitude >= 2^-53
     const double z = s * s;
     double R = 0x1.642c8590b2164p-4;
     R = SMC_FMAK(R, z, 0x1.8618618618618p-4);
@@ -215,8 +259,8 @@ SMC_HD double sp_log(double x) {
 SMC_HD void sp_sincos2pi(double u, double& c, double& s) {
     const double a = 8.0 * u;
     const int oct = (int)a;
-    double g = a - (double)oct;
-    if (oct & 1) g = 1.0 - g;
+    // g = a - oct in the even octants, 1 - (a - oct) in the odd ones: |(oct rounded up to even) - a|, exact either way
+    const double g = fabs((double)(oct + (oct & 1)) - a);
     const double y = g * PIO4;
     const double z = y * y;
     double ps = 0x1.952c77030ad4ap-49;
@@ -241,10 +285,12 @@ SMC_HD void sp_sincos2pi(double u, double& c, double& s) {
     const bool swap = ((oct + 1) & 2) != 0;
     double cc = swap ? sy : cy;
     double ss = swap ? cy : sy;
-    if ((oct + 2) & 4) cc = -cc;
-    if (oct & 4) ss = -ss;
-    c = cc;
-    s = ss;
+    // cc = -cc in the octants 2..5, ss = -ss in 4..7: bit 2 of oct + 2 / of oct moved onto the sign bit
+    const uint64_t cb = d2bits(cc), sb = d2bits(ss);
+    const uint32_t ch = xor_and((uint32_t)(cb >> 32), ((uint32_t)oct << 29) + 0x40000000u, 0x80000000u);
+    const uint32_t sh = xor_and((uint32_t)(sb >> 32), (uint32_t)oct << 29, 0x80000000u);
+    c = bits2d(((uint64_t)ch << 32) | (uint32_t)cb);
+    s = bits2d(((uint64_t)sh << 32) | (uint32_t)sb);
 }
 
 // four Philox words -> (z0, z1) iid N(0,1); z0 belongs to particle 2p, z1 to 2p+1
@@ -253,7 +299,8 @@ SMC_HD void box_muller(const u32x4& w, double& z0, double& z1) {
     const uint64_t n2 = (((uint64_t)w.v[3] << 32) | w.v[2]) >> 11;
     const double u1 = (double)(n1 + 1) * TWO_M53;
     const double u2 = (double)n2 * TWO_M53;
-    const double r = sqrt(-2.0 * sp_log_normal(u1, 0));   // u1 in [2^-53, 1]: positive, finite, normal
+    // u1 in [2^-53, 1] (positive, finite, normal): -2 log u1 is -0.0 (u1 = 1) or in [2.2e-16, 73.5]
+    const double r = sqrt_moderate_or_negzero(-2.0 * sp_log_normal(u1, 0));
     double c, s;
     sp_sincos2pi(u2, c, s);
     z0 = r * c;
