@@ -474,7 +474,9 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     // exp(logw) = p 2^k for every particle: independent of the maximum, so it overlaps the reduction
-    constexpr int DEAD = (int)0x80000000;
+    // a dead particle (NaN, infinite or absurd log-weight) takes p = 0 and the exponent DEAD = -2^30, below every live one
+    // (lw_alive: |k| < 2^30), so that k - kb never wraps: nothing after the maximum has to ask again who is alive
+    constexpr int DEAD = -(1 << 30);
     double p[NP][2];
     int kk[NP][2];
     int kloc = DEAD;
@@ -485,7 +487,8 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
             const double l = lw[k][j];
             const bool alive = lw_alive(l);
             double kq;
-            p[k][j] = sp_exp_parts(alive ? l : 0.0, kq);
+            const double pe = sp_exp_parts(l, kq);   // garbage for a dead particle: dropped here
+            p[k][j] = alive ? pe : 0.0;
             // keep the polynomial HERE (the compiler otherwise sinks it behind the barrier into
             // divergent per-particle branches and re-materialises its constants in each of them)
             asm volatile("" : "+v"(p[k][j]));
@@ -502,11 +505,11 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     for (int k = 0; k < NP; ++k) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            // fix_weight_i(p, k - kb, FIX_BITS), branch-free (same value: the clamp only acts where q = 0)
-            const int dk = (kk[k][j] != DEAD) ? kk[k][j] - kbi : -1024;
-            const int ek = dk > -(FIX_BITS + 8) ? FIX_BITS + dk : -8;
-            const uint64_t qv = d2bits(scale2(p[k][j], ek) + 0x1p52) & 0x000fffffffffffffULL;
-            const uint64_t qq = dk >= -(FIX_BITS + 2) ? qv : 0;
+            // fix_weight_i(p, k - kb, FIX_BITS), branch-free: the exponent is clamped at -8, where p 2^-8 < 1/2 rounds to the
+            // 0 that fix_weight_i returns below -(FIX_BITS + 2), and between the two p 2^ek <= 1.42 / 8 rounds to 0 as well
+            const int dk = kk[k][j] - kbi;   // <= 0, >= -2^31
+            const int ek = (dk > -(FIX_BITS + 8) ? dk : -(FIX_BITS + 8)) + FIX_BITS;
+            const uint64_t qq = d2bits(scale2(p[k][j], ek) + 0x1p52) & 0x000fffffffffffffULL;
             q[k][j] = qq;
             if (want_s2) s2 = add128(s2, sq128(qq));
         }

@@ -224,9 +224,12 @@ SMC_HD uint64_t fix_weight_i(double p, int dk, int bits) {
 // log(x) for x positive, finite and normal (no special cases to test): the body of sp_log
 SMC_HD double sp_log_normal(double x, int e0) {
     const uint64_t b = d2bits(x);
-    int e = e0 + (int)((b >> 52) & 0x7ff) - 1023;
-    double m = bits2d((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);
-    if (m > SQRT2) { m *= 0.5; e += 1; }
+    // m in (sqrt(1/2), sqrt(2)], x = m 2^e: the mantissa bits decide (m > sqrt 2 as doubles of equal exponent), and the
+    // exponent field of m is written directly (0x3fe halves it)
+    const uint64_t mant = b & 0x000fffffffffffffULL;
+    const bool up = mant > (0x3ff6a09e667f3bcdULL & 0x000fffffffffffffULL);
+    const int e = e0 + (int)((b >> 52) & 0x7ff) - 1023 + (up ? 1 : 0);
+    const double m = bits2d(mant | (up ? 0x3fe0000000000000ULL : 0x3ff0000000000000ULL));
     const double f = m - 1.0;
     const double s = div_moderate(f, 2.0 + f);   // f in [-0.2929, 0.4143]: zero or of magnitude >= 2^-53
     const double z = s * s;
@@ -295,10 +298,10 @@ SMC_HD void sp_sincos2pi(double u, double& c, double& s) {
 
 // four Philox words -> (z0, z1) iid N(0,1); z0 belongs to particle 2p, z1 to 2p+1
 SMC_HD void box_muller(const u32x4& w, double& z0, double& z1) {
-    const uint64_t n1 = (((uint64_t)w.v[1] << 32) | w.v[0]) >> 11;
-    const uint64_t n2 = (((uint64_t)w.v[3] << 32) | w.v[2]) >> 11;
-    const double u1 = (double)(n1 + 1) * TWO_M53;
-    const double u2 = (double)n2 * TWO_M53;
+    // u1 = (n1 + 1) 2^-53, u2 = n2 2^-53 with n = (hi:lo) >> 11 = hi 2^21 + (lo >> 11): two exact terms whose sum is
+    // representable, so one fma gives it exactly (instead of a 64-bit shift, a 64-bit add and a 64-bit conversion)
+    const double u1 = fma((double)w.v[1], 0x1p-32, (double)((w.v[0] >> 11) + 1u) * TWO_M53);
+    const double u2 = fma((double)w.v[3], 0x1p-32, (double)(w.v[2] >> 11) * TWO_M53);
     // u1 in [2^-53, 1] (positive, finite, normal): -2 log u1 is -0.0 (u1 = 1) or in [2.2e-16, 73.5]
     const double r = sqrt_moderate_or_negzero(-2.0 * sp_log_normal(u1, 0));
     double c, s;
