@@ -738,11 +738,14 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     // this thread's child indices relative to the workgroup's first child (masked children j >= n take
     // the last real child's target: they are never stored as real particles)
     const uint32_t m_blk = (seg0 + SEG < n32 ? seg0 + SEG : n32) - seg0;   // children of this block (>= 1)
+    const bool ragged = seg0 + SEG > n32;   // workgroup-uniform: only the filter's last block can hold masked children
     uint32_t kk[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const uint32_t j = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
-        kk[i] = (j < n32 ? j : n32 - 1) - seg0;
+    for (int i = 0; i < NQ; ++i) kk[i] = 2 * (tid + (i >> 1) * THREADS) + (i & 1);
+    if (ragged) {   // a real branch (the asm statement keeps it from being flattened into selects every block would pay)
+        asm volatile("; ragged");
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) kk[i] = (seg0 + kk[i] < n32 ? seg0 + kk[i] : n32 - 1) - seg0;
     }
     uint64_t Tg[NQ];   // MULTI: the children's targets in table units; after the segment lookup, the in-segment thresholds
 
@@ -900,7 +903,9 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
                 }
                 bseg[i] = spec_lo + r;
                 Sseg[i] = 0;
-                Tg[i] = sys_threshold(Tg[i] - base, shc);   // (C >> sh) > T - base  <=>  C > threshold
+                // (C >> sh) > T - base  <=>  C > sys_threshold(T - base, sh); the chosen segment holds mass (its table entry is
+                // positive, or the child would have passed it), so its shift is below 64 and the formula needs no guard
+                Tg[i] = ((Tg[i] - base + 1) << shc) - 1;
             }
         } else {
             for (int s = w0 >> 1; s >= 1; s >>= 1) {
@@ -1028,8 +1033,11 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
     for (int i = 0; i < NQ; ++i) {
         const uint32_t own = seg0 + 2 * (tid + (i >> 1) * THREADS) + (i & 1);
         uint32_t a = (uint32_t)bseg[i] * (uint32_t)SEG + (uint32_t)pos[i];
-        a = alive ? a : own;                // collapsed filter: identity
-        a = a < n32 ? a : n32 - 1;          // only masked children (j >= n) can land there
+        if (!alive || ragged) {   // workgroup-uniform and rare
+            asm volatile("; collapsed or ragged");
+            a = alive ? a : own;                // collapsed filter: identity
+            a = a < n32 ? a : n32 - 1;          // only masked children (j >= n) can land there
+        }
         anc[i] = a;
 #pragma unroll
         for (int c = 0; c < D; ++c) xp[i][c] = SMC_ABL(v, 1) ? 0.25 * (double)(a & 7) : xprev[((size_t)c * v.ntheta + th) * v.npad + a];
@@ -1047,14 +1055,23 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 #pragma unroll
             for (int c = 0; c < D; ++c) zz[c] = z[k][c][j];
             model_transition<MODEL>(prm, xp[2 * k + j], zz, xn[j]);
-            const bool valid = (i0 + j) < n32;
-            lw[k][j] = valid ? model_logobs<MODEL>(prm, xn[j], y) : nan_mask();
+            lw[k][j] = model_logobs<MODEL>(prm, xn[j], y);
+        }
+        if (ragged) {   // masked children: NaN weight, zero state
+            asm volatile("; ragged");
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (i0 + j >= n32) {
+                    lw[k][j] = nan_mask();
+#pragma unroll
+                    for (int c = 0; c < D; ++c) xn[j][c] = 0.0;
+                }
         }
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             double2 o;
-            o.x = (i0 < n32) ? xn[0][c] : 0.0;
-            o.y = (i0 + 1 < n32) ? xn[1][c] : 0.0;
+            o.x = xn[0][c];
+            o.y = xn[1][c];
             store_out(reinterpret_cast<double2*>(v.x[nxt] + ((size_t)c * v.ntheta + th) * v.npad + i0), o);
         }
         if (v.anc) {
