@@ -497,9 +497,10 @@ static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_
         HIPCHK(do_init(h, y0));
         h->t = 1; h->inited = true; h->emitted = false;
         for (int64_t t = 1; t < T; ++t) {
+            const int emit = h->v.want_s2 ? 1 : 2;   // 2: the records of step t-1 carry no sum of squares - (logmu, 0) from the totals alone
             if (t == T - 1) h->v.want_s2 = 1;
             HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
-            HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
+            HIPCHK(do_step(h, (uint32_t)t, emit, 0.0));
             h->cur ^= 1; h->t += 1;
         }
         rc = emit_if_needed(h);
@@ -754,22 +755,26 @@ extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, in
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
     h->v.y = h->d_y; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     h->cur = 0;
+    h->v.want_s2 = 0;   // exactly the launches of log_likelihood without traces (enqueue_log_likelihood)
     HIPCHK(do_init(h, y[0]));
     h->t = 1; h->inited = true; h->emitted = false;
     const int64_t stride = (T - 1) / nsample;   // >= G
     int k = 0, open_left = 0;
     for (int64_t t = 1; t < T; ++t) {
+        const int emit = h->v.want_s2 ? 1 : 2;
+        if (t == T - 1) h->v.want_s2 = 1;
         HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
         if (!open_left && k < nsample && ((t - 1) % stride) == (stride - G) / 2) {
             HIPCHK(hipEventRecord(e0[k], h->stream));
             open_left = G;
         }
-        HIPCHK(do_step(h, (uint32_t)t, 1, 0.0));
+        HIPCHK(do_step(h, (uint32_t)t, emit, 0.0));
         if (open_left && --open_left == 0) { HIPCHK(hipEventRecord(e1[k], h->stream)); ++k; }
         h->cur ^= 1; h->t += 1;
     }
     if (open_left) { HIPCHK(hipEventRecord(e1[k], h->stream)); }   // (cannot happen: every bracket fits its stride)
     rc = emit_if_needed(h);
+    h->v.want_s2 = 1;
     h->v.y = nullptr;
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));

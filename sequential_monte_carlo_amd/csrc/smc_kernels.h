@@ -113,6 +113,9 @@ struct FilterView {
 // workgroups share a CU; the arbiter otherwise favours the older one, which then finishes ~4 us before its neighbour
 // and leaves it to run the tail of the launch alone at half occupancy.  With this rule whoever has fallen behind catches
 // up and both end together (measured on C2: end-time spread of the workgroups 4.8 -> 2.1 us, 17.65 -> 16.3 us per step).
+#ifndef SMC_NORMALS_EARLY
+#define SMC_NORMALS_EARLY 0
+#endif
 #define SMC_PRIO(ph) __builtin_amdgcn_s_setprio((short)(3 - (ph)))
 
 // ---------------------------------------------------------------------------------------------
@@ -412,7 +415,7 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
 // numbers are the same integers table_prologue produces.  P0 = Dcum[lo-1] (0 for lo = 0), Dc[r] = Dcum[lo+r].
 template <int THREADS, int NE>
 __device__ __forceinline__ uint64_t window_prologue(const FilterView& v, uint64_t* scr, const TablePre& pre, int lo, uint64_t& P0,
-                                                    uint64_t (&Dc)[NE], int (&shw)[NE]) {
+                                                    uint64_t (&Dc)[NE], int (&shw)[NE], double& Kout) {
     constexpr int NW = THREADS / WAVE;
     constexpr int DEADK = (int)0x80000000;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -420,6 +423,7 @@ __device__ __forceinline__ uint64_t window_prologue(const FilterView& v, uint64_
     const int ki = (!live || pre.k1 == -inf()) ? DEADK : (int)pre.k1;
     const int km = block_max_i32<THREADS>(ki, (int*)scr);            // barrier 1
     const double K = km == DEADK ? -inf() : (double)km;
+    Kout = K;
     int sh = 64;
     uint64_t Q = 0;
     if (live) { sh = seg_shift(K, pre.k1, v.SH); Q = seg_Q(pre.S1, sh); }
@@ -597,6 +601,27 @@ __device__ __forceinline__ void emit_own(const FilterView& v, int th, const SegR
     v.last_ess[th] = ess;
     v.last_K[th] = rec.kb;
     v.last_D[th] = D;
+    if (v.trace_logmu) v.trace_logmu[(size_t)t_emit * v.ntheta + th] = logmu;
+    if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
+    const double z = first_emit ? logmu : v.logZ[th] + logmu;
+    v.logZ[th] = z;
+    if (v.host_out) {
+        v.host_out[th] = z;
+        v.host_out[(size_t)v.ntheta + th] = logmu;
+        v.host_out[2 * (size_t)v.ntheta + th] = ess;
+    }
+}
+
+// (logmu, ess = 0) of the previous step from the totals (K, Dtot) alone: what table_prologue's emit produces when the
+// records carry no sum of squares (want_s2 = 0 at that step: log_likelihood without traces, particles.jl:142 discards
+// ess).  Thread 0 of the emitting workgroup; no table, no extra barrier.
+__device__ __forceinline__ void emit_from_totals(const FilterView& v, int th, double K, uint64_t Dtot, bool first_emit, uint32_t t_emit) {
+    double logmu, ess;
+    combine_outputs(K, Dtot, 0, v.SH, v.n, logmu, ess);
+    v.last_logmu[th] = logmu;
+    v.last_ess[th] = ess;
+    v.last_K[th] = K;
+    v.last_D[th] = Dtot;
     if (v.trace_logmu) v.trace_logmu[(size_t)t_emit * v.ntheta + th] = logmu;
     if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
     const double z = first_emit ? logmu : v.logZ[th] + logmu;
@@ -789,7 +814,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             else box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[k][c][0], z[k][c][1]);
             // systematic: keep the normals HERE, under the load latencies.  multinomial: measured faster when the
             // compiler sinks them next to their use, where they fill the waits of the LDS search
-            if (SYS) asm volatile("" : "+v"(z[k][c][0]), "+v"(z[k][c][1]));
+            if (SYS || SMC_NORMALS_EARLY) asm volatile("" : "+v"(z[k][c][0]), "+v"(z[k][c][1]));
         }
     }
 
@@ -813,13 +838,22 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         // What this workgroup needs of the segment table of the weights being resampled.  Usual case: only its speculative
         // window (window_prologue: no table in LDS).  The workgroup that emits (logmu, ess) of the previous step, filters with
         // more segments than threads, and windows that turn out too narrow build the whole table (table_prologue).
+        // emit_prev = 2: the records of the previous step carry no sum of squares, (logmu, ess = 0) follow from the totals every
+        // workgroup computes anyway - the emitting workgroup then is no slower than the others (the full table made it, and the
+        // workgroup sharing its CU, end 0.75 us after everybody else: the whole launch waited for them)
         const bool emitter = emit_prev && sb == 0;
+        const bool emit_totals = emitter && emit_prev == 2;
         const int s_hi = spec_lo + NSTAGE - 1 < v.nseg - 1 ? spec_lo + NSTAGE - 1 : v.nseg - 1;
-        const bool use_fast = SPEC && !emitter && v.nseg_p2 <= THREADS;      // workgroup-uniform
+        const bool use_fast = SPEC && (!emitter || emit_totals) && v.nseg_p2 <= THREADS;      // workgroup-uniform
         uint64_t P0 = 0, Dc[NSTAGE];
         int shw[NSTAGE];
-        if (use_fast) alive = window_prologue<THREADS, NSTAGE>(v, L.scr, tpre, spec_lo, P0, Dc, shw);
-        else alive = table_prologue<THREADS>(v, cur, th, L, emitter, t == 1u, t - 1u, &tpre);
+        if (use_fast) {
+            double Kw;
+            alive = window_prologue<THREADS, NSTAGE>(v, L.scr, tpre, spec_lo, P0, Dc, shw, Kw);
+            if (emit_totals && tid == 0) emit_from_totals(v, th, Kw, alive, t == 1u, t - 1u);
+        } else {
+            alive = table_prologue<THREADS>(v, cur, th, L, emitter, t == 1u, t - 1u, &tpre);
+        }
         SMC_STAMP(v, 1);
         SMC_PRIO(1);
         // targets of the first and last child of the block, in table units.  multinomial: the block's n
