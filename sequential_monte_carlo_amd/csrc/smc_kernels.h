@@ -139,14 +139,33 @@ __device__ __forceinline__ uint64_t dpp_u64z(uint64_t v) {   // lanes without a 
     }
     return ((uint64_t)hi << 32) | lo;
 }
+// v + (v of the lane the DPP control names; 0 where there is none), 64-bit: the cross-lane read rides on the add and the
+// add-with-carry themselves (two VALU instructions; moving the two halves first and adding then took five to seven).
+// The leading s_nop covers the two wait states between a VALU write of a register and a DPP read of it, whatever precedes.
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_add_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#define SMC_DPP_ADD64(MOD)                                                                                  \
+    asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " MOD "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " MOD \
+                 : "+v"(lo), "+v"(hi) : : "vcc")
+    static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "DPP control");
+    if (CTRL == 0x111) SMC_DPP_ADD64("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x112) SMC_DPP_ADD64("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x114) SMC_DPP_ADD64("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x118) SMC_DPP_ADD64("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x142) SMC_DPP_ADD64("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    if (CTRL == 0x143) SMC_DPP_ADD64("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef SMC_DPP_ADD64
+    return ((uint64_t)hi << 32) | lo;
+}
 // inclusive prefix sum over the 64 lanes of a wave
 __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int /*lane*/) {
-    v += dpp_u64z<0x111, 0xf>(v);
-    v += dpp_u64z<0x112, 0xf>(v);
-    v += dpp_u64z<0x114, 0xf>(v);
-    v += dpp_u64z<0x118, 0xf>(v);
-    v += dpp_u64z<0x142, 0xa>(v);
-    v += dpp_u64z<0x143, 0xc>(v);
+    v = dpp_add_u64<0x111>(v);
+    v = dpp_add_u64<0x112>(v);
+    v = dpp_add_u64<0x114>(v);
+    v = dpp_add_u64<0x118>(v);
+    v = dpp_add_u64<0x142>(v);
+    v = dpp_add_u64<0x143>(v);
     return v;
 }
 // 32-bit inclusive prefix sum (the compiler folds each move into one v_add_u32_dpp)
@@ -179,10 +198,10 @@ template <int NW>
 __device__ __forceinline__ void wave_totals(const uint64_t* tot, int lane, int wave, uint64_t& off, uint64_t& all) {
     static_assert(NW >= 1 && NW <= 16 && (NW & (NW - 1)) == 0, "wave count");
     uint64_t t = tot[lane & (NW - 1)];
-    if (NW > 1) t += dpp_u64z<0x111, 0xf>(t);
-    if (NW > 2) t += dpp_u64z<0x112, 0xf>(t);
-    if (NW > 4) t += dpp_u64z<0x114, 0xf>(t);
-    if (NW > 8) t += dpp_u64z<0x118, 0xf>(t);
+    if (NW > 1) t = dpp_add_u64<0x111>(t);
+    if (NW > 2) t = dpp_add_u64<0x112>(t);
+    if (NW > 4) t = dpp_add_u64<0x114>(t);
+    if (NW > 8) t = dpp_add_u64<0x118>(t);
     const int ws = __builtin_amdgcn_readfirstlane(wave);
     all = readlane_u64(t, NW - 1);
     const uint64_t prev = readlane_u64(t, ws > 0 ? ws - 1 : 0);
@@ -439,10 +458,10 @@ __device__ __forceinline__ uint64_t window_prologue(const FilterView& v, uint64_
     __syncthreads();                                                 // barrier 2
     // totals of the waves: lanes 0..NW-1 of every wave scan them (DPP), Dtot and the offset of the wave holding segment lo-1
     uint64_t t = wt[lane & (NW - 1)];
-    if (NW > 1) t += dpp_u64z<0x111, 0xf>(t);
-    if (NW > 2) t += dpp_u64z<0x112, 0xf>(t);
-    if (NW > 4) t += dpp_u64z<0x114, 0xf>(t);
-    if (NW > 8) t += dpp_u64z<0x118, 0xf>(t);
+    if (NW > 1) t = dpp_add_u64<0x111>(t);
+    if (NW > 2) t = dpp_add_u64<0x112>(t);
+    if (NW > 4) t = dpp_add_u64<0x114>(t);
+    if (NW > 8) t = dpp_add_u64<0x118>(t);
     const uint64_t Dtot = readlane_u64(t, NW - 1);
     uint64_t p0 = 0;
     if (lo > 0) {                                                    // workgroup-uniform
@@ -536,10 +555,10 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     uint64_t tt = 0;
     if (MERGED) {
         tt = wtot[lane & (NP * NW - 1)];
-        tt += dpp_u64z<0x111, 0xf>(tt);
-        if (NP * NW > 2) tt += dpp_u64z<0x112, 0xf>(tt);
-        if (NP * NW > 4) tt += dpp_u64z<0x114, 0xf>(tt);
-        if (NP * NW > 8) tt += dpp_u64z<0x118, 0xf>(tt);
+        tt = dpp_add_u64<0x111>(tt);
+        if (NP * NW > 2) tt = dpp_add_u64<0x112>(tt);
+        if (NP * NW > 4) tt = dpp_add_u64<0x114>(tt);
+        if (NP * NW > 8) tt = dpp_add_u64<0x118>(tt);
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
