@@ -127,18 +127,6 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp_u64z(uint64_t v) {   // lanes without a source read 0
-    uint32_t lo, hi;
-    if (ROW_MASK == 0xf) {   // every row enabled: bound_ctrl supplies the zeros, no "old" register to clear
-        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, true);
-        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, true);
-    } else {
-        lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)v);
-        hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
-    }
-    return ((uint64_t)hi << 32) | lo;
-}
 // v + (v of the lane the DPP control names; 0 where there is none), 64-bit: the cross-lane read rides on the add and the
 // add-with-carry themselves (two VALU instructions; moving the two halves first and adding then took five to seven).
 // The leading s_nop covers the two wait states between a VALU write of a register and a DPP read of it, whatever precedes.
@@ -226,18 +214,32 @@ __device__ __forceinline__ U128 sq128(uint64_t q) {
     r.lo = q * q;
     return r;
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ U128 dpp_u128z(U128 v) {
-    return U128{dpp_u64z<CTRL, ROW_MASK>(v.lo), dpp_u64z<CTRL, ROW_MASK>(v.hi)};
+// the 128-bit version of dpp_add_u64: one add and three adds-with-carry, each reading its other lane itself
+template <int CTRL>
+__device__ __forceinline__ U128 dpp_add_u128(U128 v) {
+    uint32_t w0 = (uint32_t)v.lo, w1 = (uint32_t)(v.lo >> 32), w2 = (uint32_t)v.hi, w3 = (uint32_t)(v.hi >> 32);
+#define SMC_DPP_ADD128(MOD)                                                                                       \
+    asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " MOD "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " MOD    \
+                 "\n\tv_addc_co_u32_dpp %2, vcc, %2, %2, vcc " MOD "\n\tv_addc_co_u32_dpp %3, vcc, %3, %3, vcc " MOD \
+                 : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : : "vcc")
+    static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "DPP control");
+    if (CTRL == 0x111) SMC_DPP_ADD128("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x112) SMC_DPP_ADD128("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x114) SMC_DPP_ADD128("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x118) SMC_DPP_ADD128("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    if (CTRL == 0x142) SMC_DPP_ADD128("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    if (CTRL == 0x143) SMC_DPP_ADD128("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef SMC_DPP_ADD128
+    return U128{((uint64_t)w1 << 32) | w0, ((uint64_t)w3 << 32) | w2};
 }
 // total over the wave, valid in every lane
 __device__ __forceinline__ U128 wave_sum128(U128 v) {
-    v = add128(v, dpp_u128z<0x111, 0xf>(v));
-    v = add128(v, dpp_u128z<0x112, 0xf>(v));
-    v = add128(v, dpp_u128z<0x114, 0xf>(v));
-    v = add128(v, dpp_u128z<0x118, 0xf>(v));
-    v = add128(v, dpp_u128z<0x142, 0xa>(v));
-    v = add128(v, dpp_u128z<0x143, 0xc>(v));
+    v = dpp_add_u128<0x111>(v);
+    v = dpp_add_u128<0x112>(v);
+    v = dpp_add_u128<0x114>(v);
+    v = dpp_add_u128<0x118>(v);
+    v = dpp_add_u128<0x142>(v);
+    v = dpp_add_u128<0x143>(v);
     return U128{readlane_u64(v.lo, WAVE - 1), readlane_u64(v.hi, WAVE - 1)};
 }
 // max of an int over the wave, valid in every lane
