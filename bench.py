@@ -48,7 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# secondary (ALU) ceiling: 256 CUs x 4 SIMDs; measured by scripts/dbg/valu_rates.hip on this pool: 4.3-4.7 cycles
+# secondary (ALU) ceiling: 256 CUs x 4 SIMDs; measured by scripts/dbg/valu_rate.hip on this pool: 4.3-4.7 cycles
 # per wave64 f64 / 64-bit-integer VALU instruction with 4 waves per SIMD, core clock 2.2-2.4 GHz under VALU load
 N_SIMD, VALU_CYCLES_PER_INST, CLOCK_GHZ = 1024, 4.4, 2.3
 

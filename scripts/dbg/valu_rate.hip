@@ -2,6 +2,15 @@
 // Every test runs ITER x 8 independent chains of one instruction per lane, 8 waves per SIMD on every CU, and prints the
 // time per wave-instruction per SIMD relative to v_xor_b32 (= one full-rate slot).
 //   hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_rate scripts/dbg/valu_rate.hip && /tmp/valu_rate
+// Measured on an MI355X of this pool (one slot = 1.076 ns per wave-instruction per SIMD, i.e. 2.5 cycles at 2.3-2.4 GHz):
+//   1.0   v_add_u32 v_sub_u32 v_xor/and/or_b32 v_bitop3_b32 v_mov_b32 v_lshrrev_b32 v_fma/mul/add_f32
+//   1.6-1.9  v_fma_f64 1.88 v_mul_f64 1.85 v_add_f64 1.7 v_mad_u64_u32 1.72 v_mul_lo_u32 1.8 v_mul_hi_u32 1.67 v_cndmask_b32 1.63
+//         v_cmp_* 1.67 v_lshlrev_b32 1.6 v_lshl_add_u32/u64 1.7 v_lshl/lshrrev_b64 1.65 v_add3_u32 v_max/min_i32 v_cvt_* v_ldexp_f64
+//         v_mov_b64 v_readlane_b32 and every DPP form (v_mov_b32_dpp, v_add_u32_dpp) 1.65
+//   3.2   v_exp_f32        6.3   v_rcp_f64 v_rsq_f64 v_sqrt_f64 v_trig_preop_f64
+//   (v_cndmask_b32 with a VCC nobody has written in the kernel shows 8.8: an artefact of this test, 1.6 after a v_cmp)
+// scripts/dbg/isa_cost.py weights an ISA listing with this table: the loop of k_resident (LG) came to 978 slots per wave and
+// step = 4.2 us at four waves per SIMD, the measured time per step - the batched kernel is bound by VALU issue, nothing else.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -45,6 +45,14 @@ def test_device_math_is_bit_exact(L, ob):
     assert same(L.device_math(5, a, b), a / b)                        # IEEE divide
     wa = rng.integers(0, 2**64, 4000, dtype=np.uint64)
     wb = rng.integers(0, 2**64, 4000, dtype=np.uint64)
+    # the corners of Box-Muller: u1 = 1 (radius -0.0: the square root's refinement alone would give NaN), u1 = 2^-53, the
+    # carry of (lo >> 11) + 1 into the high word, mantissas next to sqrt 2, and u2 on / next to every octant boundary
+    edge_a = [2**64 - 1, 0, 2**32 - 1, (2**32 - 1) << 11, 0x6A09E667F3BCD << 11 | 0x7FF, (0x6A09E667F3BCD + 1) << 11, 1 << 63, (1 << 63) - 1]
+    edge_b = [k << 61 for k in range(8)] + [(k << 61) - (1 << 11) for k in range(1, 8)] + [(k << 61) + (1 << 11) for k in range(8)] + [2**64 - 1]
+    wa[:len(edge_a)] = np.array(edge_a, dtype=np.uint64)
+    wb[100:100 + len(edge_b)] = np.array(edge_b, dtype=np.uint64)
+    wa[100:100 + len(edge_b)] = np.uint64(2**64 - 1) >> np.uint64(3)
+    wb[:len(edge_a)] = np.array([k << 61 for k in range(8)], dtype=np.uint64)
     z0 = L.device_math(3, wa.view(np.float64), wb.view(np.float64))
     z1 = L.device_math(4, wa.view(np.float64), wb.view(np.float64))
     ref = np.array([ob.box_muller([int(p) & 0xFFFFFFFF, int(p) >> 32, int(q) & 0xFFFFFFFF, int(q) >> 32])
