@@ -198,12 +198,24 @@ SMC_HD double sp_exp_parts(double x, double& kout) {
 }
 
 SMC_HD double sp_exp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // branch-free on the device (as three nested divergent branches the calls of a thread could not overlap): the body runs on
+    // whatever x is - nothing in it traps - and the two range cases are selected afterwards; a NaN passes both comparisons
+    // and comes out of the arithmetic as itself
+    double k;
+    const double p = sp_exp_parts(x, k);
+    double r = scale2(p, (int)k);    // x in (-708, 709]: a normal number
+    r = x > 709.0 ? inf() : r;
+    r = x <= -708.0 ? 0.0 : r;
+    return r;
+#else
     if (x != x) return x;
     if (!(x > -708.0)) return 0.0;
     if (x > 709.0) return inf();
     double k;
     const double p = sp_exp_parts(x, k);
     return scale2(p, (int)k);        // x > -708: the result is a normal number
+#endif
 }
 
 // a log-weight takes part in the normalisation iff it is a number of sane magnitude
