@@ -129,12 +129,14 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
 }
 // v + (v of the lane the DPP control names; 0 where there is none), 64-bit: the cross-lane read rides on the add and the
 // add-with-carry themselves (two VALU instructions; moving the two halves first and adding then took five to seven).
-// The leading s_nop covers the two wait states between a VALU write of a register and a DPP read of it, whatever precedes.
+// The leading s_nop covers the two wait states between a VALU write of a register and a DPP read of it, whatever precedes;
+// the one between the add and the add-with-carry the two wait states gfx940-class hardware wants between a VALU write of VCC
+// and a VALU read of it (the compiler puts the same s_nop 1 between its own v_add_co / v_addc_co pairs).
 template <int CTRL>
 __device__ __forceinline__ uint64_t dpp_add_u64(uint64_t v) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
 #define SMC_DPP_ADD64(MOD)                                                                                  \
-    asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " MOD "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " MOD \
+    asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " MOD "\n\ts_nop 1\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " MOD \
                  : "+v"(lo), "+v"(hi) : : "vcc")
     static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "DPP control");
     if (CTRL == 0x111) SMC_DPP_ADD64("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
@@ -219,8 +221,8 @@ template <int CTRL>
 __device__ __forceinline__ U128 dpp_add_u128(U128 v) {
     uint32_t w0 = (uint32_t)v.lo, w1 = (uint32_t)(v.lo >> 32), w2 = (uint32_t)v.hi, w3 = (uint32_t)(v.hi >> 32);
 #define SMC_DPP_ADD128(MOD)                                                                                       \
-    asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " MOD "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " MOD    \
-                 "\n\tv_addc_co_u32_dpp %2, vcc, %2, %2, vcc " MOD "\n\tv_addc_co_u32_dpp %3, vcc, %3, %3, vcc " MOD \
+    asm volatile("s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " MOD "\n\ts_nop 1\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " MOD \
+                 "\n\ts_nop 1\n\tv_addc_co_u32_dpp %2, vcc, %2, %2, vcc " MOD "\n\ts_nop 1\n\tv_addc_co_u32_dpp %3, vcc, %3, %3, vcc " MOD \
                  : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : : "vcc")
     static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "DPP control");
     if (CTRL == 0x111) SMC_DPP_ADD128("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
