@@ -64,13 +64,17 @@ WORKLOADS = {
     "c5": (3, UC, 512, 1024, 200, "UCSV batched inner filters Ntheta=512/GPU x Nx=1024 T=200 (configs[4] shape)"),
 }
 SAMPLERS = ("dt", "smc2", "c5dt")
+# one step of c2 / c3 is 13 / 66 ms of GPU work, of c4 / c5 0.7 / 1.4 ms, of the samplers 7 - 12 ms
+DEFAULT_WARMUP = {"c2": 3, "c3": 1, "c4": 60, "c5": 30, "dt": 6, "smc2": 5, "c5dt": 5}
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed warm-up steps; default per workload (DEFAULT_WARMUP): enough to precede the timed region by "
+                         ">= 40 ms of GPU work - after idling the first ~50 ms run at lower clocks (k_resident 0.72 -> 0.64 ms)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + list(SAMPLERS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="sampler workloads: weak = 512 parameter particles per GPU; strong = --n-theta in total")
@@ -86,7 +90,10 @@ def parse_args(argv=None):
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a 1-GPU box / on CPU")
     ap.add_argument("--dry-launch", action="store_true",
                     help="form the process group, report the ranks seen, run nothing (no GPU needed with gloo)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.warmup is None:
+        args.warmup = DEFAULT_WARMUP[args.workload]
+    return args
 
 
 # ---- launcher: `python bench.py --gpus N` without torch.distributed.run -------------------------------------

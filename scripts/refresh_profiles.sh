@@ -12,7 +12,7 @@ cp gpurun_out/pmc_c2.json gpurun_out/pmc_c4.json $O/
 cp gpurun_out/pmc_c2.json gpurun_out/pmc_c4.json profiles/
 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 for wl in c3 c4 c5; do python3 bench.py --workload $wl --no-aux > $O/bench_$wl.json 2> $O/bench_$wl.err; done
-for wl in dt smc2 c5dt; do python3 bench.py --workload $wl --steps 5 --warmup 2 > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+for wl in dt smc2 c5dt; do python3 bench.py --workload $wl --steps 5 > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 python3 bench.py --resampler systematic --no-aux --no-cpu-baseline > $O/bench_c2_systematic.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c2 -o kt -- python3 bench.py --steps 3 --no-aux --no-cpu-baseline > $O/kt_c2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c4 -o kt -- python3 bench.py --workload c4 --steps 3 --no-aux --no-cpu-baseline > $O/kt_c4.log 2>&1

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <algorithm>
+#include <map>
 #include <vector>
 
 using namespace smc;
@@ -289,6 +290,45 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
 #ifdef SMC_ABLATE
+    if (h->v.dbg && h->v.nseg == 1) {   // placement and lifetime of the workgroups of the LAST k_resident launch
+        const size_t nwg = (size_t)h->v.ntheta;
+        std::vector<unsigned long long> st(nwg * 8);
+        (void)hipMemcpy(st.data(), h->v.dbg, nwg * 64, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        std::map<unsigned long long, std::vector<size_t>> bycu;
+        size_t nact = 0;
+        for (size_t w = 0; w < nwg; ++w) {
+            if (!st[w * 8 + 1]) continue;
+            ++nact;
+            if (st[w * 8] < t0) t0 = st[w * 8];
+            if (st[w * 8 + 1] > t1) t1 = st[w * 8 + 1];
+            const unsigned long long hw = st[w * 8 + 2];
+            const unsigned long long key = ((hw >> 32) & 0xf) << 16 | ((hw >> 8) & 0xff);   // (xcc, se/sh/cu)
+            bycu[key].push_back(w);
+        }
+        int hist[9] = {0};
+        double life[9] = {0};
+        for (auto& kv : bycu) {
+            const size_t c = kv.second.size() < 8 ? kv.second.size() : 8;
+            hist[c]++;
+            for (size_t w : kv.second) life[c] += (double)(st[w * 8 + 1] - st[w * 8]) * 0.01;
+        }
+        fprintf(stderr, "[dbg] k_resident: %zu workgroups ran on %zu CUs, span %.1f us;", nact, bycu.size(), (double)(t1 - t0) * 0.01);
+        for (int c = 1; c <= 8; ++c)
+            if (hist[c]) fprintf(stderr, "  %d CUs with %d workgroups (mean life %.1f us)", hist[c], c, life[c] / (hist[c] * c));
+        fprintf(stderr, "\n");
+        {   // start times of the workgroups sharing a CU: simultaneous or one after the other?
+            int shown = 0;
+            for (auto& kv : bycu) {
+                if (shown++ >= 4) break;
+                fprintf(stderr, "[dbg]   cu %05llx:", kv.first);
+                for (size_t w : kv.second) fprintf(stderr, " wg %zu [%.1f, %.1f]", w, (double)(st[w * 8] - t0) * 0.01, (double)(st[w * 8 + 1] - t0) * 0.01);
+                fprintf(stderr, "\n");
+            }
+        }
+        (void)hipFree(h->v.dbg);
+        h->v.dbg = nullptr;
+    }
     if (h->v.dbg) {   // phase profile of the LAST k_step launch: mean over workgroups, in microseconds
         const size_t nwg = (size_t)h->v.ntheta * h->v.nseg;
         std::vector<unsigned long long> st(nwg * 8);

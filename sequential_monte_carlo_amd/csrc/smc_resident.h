@@ -61,6 +61,13 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
     StepRec* rec = recs + (size_t)th * T;
+#ifdef SMC_ABLATE
+    if (v.dbg && tid == 0) {   // diagnostic build: where and when this workgroup runs (HW_ID: cu [11:8], sh [12], se [15:13]; XCC_ID)
+        v.dbg[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        v.dbg[(size_t)blockIdx.x * 8 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
+                                            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);
+    }
+#endif
 
     constexpr int NQ = 2 * NP;
     double xn[NP][2][D];
@@ -280,6 +287,9 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
             v.segS2lo[bout][th] = o.lo;
         }
     }
+#ifdef SMC_ABLATE
+    if (v.dbg && tid == 0) v.dbg[(size_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (WIN) return;
     __syncthreads();
     if (tid == 0) {
