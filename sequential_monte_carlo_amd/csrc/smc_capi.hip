@@ -519,10 +519,19 @@ extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
     return finish_timing(h, nullptr, logmu, ess);
 }
 
+// Restores the fields of the view that a whole-series call sets for its launches, on every exit path (an early HIPCHK return
+// must not leave the handle accumulating no sum of squares, or pointing at the series)
+struct SeriesScope {
+    FilterView& v;
+    explicit SeriesScope(FilterView& view) : v(view) {}
+    ~SeriesScope() { v.want_s2 = 1; v.y = nullptr; v.trace_logmu = nullptr; v.trace_ess = nullptr; }
+};
+
 // The launches of log_likelihood(N, y, model) (particles.jl:132-147) for every filter of the handle, enqueued on
 // its stream: nothing here waits for the device.  y must already be in h->d_y (ensure_y + copy by the caller).
 static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_trace) {
     const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
+    SeriesScope scope(h->v);
     h->v.y = h->d_y;
     h->v.trace_logmu = want_trace ? h->d_tr_logmu : nullptr;
     h->v.trace_ess = want_trace ? h->d_tr_ess : nullptr;
@@ -543,10 +552,9 @@ static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_
             HIPCHK(do_step(h, (uint32_t)t, emit, 0.0));
             h->cur ^= 1; h->t += 1;
         }
+        h->v.want_s2 = 1;
         rc = emit_if_needed(h);
     }
-    h->v.want_s2 = 1;
-    h->v.y = nullptr; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     return rc;
 }
 
@@ -793,6 +801,7 @@ extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, in
     std::vector<hipEvent_t> e0((size_t)nsample), e1((size_t)nsample);
     for (int i = 0; i < nsample; ++i) { HIPCHK(hipEventCreate(&e0[i])); HIPCHK(hipEventCreate(&e1[i])); }
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
+    SeriesScope scope(h->v);
     h->v.y = h->d_y; h->v.trace_logmu = nullptr; h->v.trace_ess = nullptr;
     h->cur = 0;
     h->v.want_s2 = 0;   // exactly the launches of log_likelihood without traces (enqueue_log_likelihood)
@@ -813,9 +822,8 @@ extern "C" int smc_time_step_kernel(smc_handle h, const double* y, int64_t T, in
         h->cur ^= 1; h->t += 1;
     }
     if (open_left) { HIPCHK(hipEventRecord(e1[k], h->stream)); }   // (cannot happen: every bracket fits its stride)
-    rc = emit_if_needed(h);
     h->v.want_s2 = 1;
-    h->v.y = nullptr;
+    rc = emit_if_needed(h);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     double sum = 0.0, mn = 1e30;
