@@ -63,6 +63,9 @@ struct smc_filter_s {
     bool pm_cfg = false;
     PmmhDev pm{};
     double* h_pm_out = nullptr;                // pinned mirror: theta [ntheta][d] | logZ [ntheta] | any [ntheta] | nrun
+    double* pm_in = nullptr;                   // ONE device block: pm.theta | pm.logZ | pm.chol | pm.nrun | pm.counts | pm.any -
+    double* h_pm_in = nullptr;                 //   a rejuvenation call fills its pinned twin and uploads it in one copy
+    size_t pm_in_words = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cur = 0;
@@ -375,11 +378,12 @@ extern "C" int smc_destroy(smc_handle h) {
     }
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
+    if (h->h_pm_in) (void)hipHostFree(h->h_pm_in);
     (void)hipFree(h->d_skip); (void)hipFree(h->d_order);
     if (h->h_win) (void)hipHostFree(h->h_win);
-    (void)hipFree(h->pm.order); (void)hipFree(h->pm.counts);
-    (void)hipFree(h->pm.theta); (void)hipFree(h->pm.prop); (void)hipFree(h->pm.logZ); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip);
-    (void)hipFree(h->pm.mask); (void)hipFree(h->pm.any); (void)hipFree(h->pm.nrun); (void)hipFree(h->pm.chol);
+    (void)hipFree(h->pm.order);
+    (void)hipFree(h->pm_in);   // pm.theta, pm.logZ, pm.chol, pm.nrun, pm.counts, pm.any live in this block
+    (void)hipFree(h->pm.prop); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip); (void)hipFree(h->pm.mask);
     if (h->d_brk) (void)hipFree(h->d_brk);
     if (h->d_q) (void)hipFree(h->d_q);
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
@@ -684,18 +688,23 @@ extern "C" int smc_pmmh_configure(smc_handle h, int d_theta, const int32_t* prio
     }
     HIPCHK(hipSetDevice(h->device));
     const size_t nt = (size_t)h->v.ntheta;
-    if (!h->pm.theta) {
-        HIPCHK(dalloc(&h->pm.theta, nt * MAX_DTHETA));
+    if (!h->pm_in) {
+        // what a rejuvenation call uploads or clears sits in ONE block (8-byte words): theta | logZ | chol | nrun | counts | any
+        const size_t w_theta = nt * MAX_DTHETA, w_chol = (size_t)MAX_DTHETA * MAX_DTHETA, w_any = (nt + 7) / 8;
+        h->pm_in_words = w_theta + nt + w_chol + 2 + w_any;
+        HIPCHK(dalloc(&h->pm_in, h->pm_in_words));
+        HIPCHK(hipHostMalloc((void**)&h->h_pm_in, h->pm_in_words * 8, hipHostMallocDefault));
+        h->pm.theta = h->pm_in;
+        h->pm.logZ = h->pm.theta + w_theta;
+        h->pm.chol = h->pm.logZ + nt;
+        h->pm.nrun = (unsigned long long*)(h->pm.chol + w_chol);
+        h->pm.counts = (int32_t*)(h->pm.nrun + 1);
+        h->pm.any = (unsigned char*)(h->pm.nrun + 2);
         HIPCHK(dalloc(&h->pm.prop, nt * MAX_DTHETA));
-        HIPCHK(dalloc(&h->pm.logZ, nt));
         HIPCHK(dalloc(&h->pm.lp, nt * 2));
         HIPCHK(dalloc(&h->pm.skip, nt));
         HIPCHK(dalloc(&h->pm.mask, nt));
-        HIPCHK(dalloc(&h->pm.any, nt));
-        HIPCHK(dalloc(&h->pm.nrun, 1));
-        HIPCHK(dalloc(&h->pm.chol, MAX_DTHETA * MAX_DTHETA));
         HIPCHK(dalloc(&h->pm.order, nt));
-        HIPCHK(dalloc(&h->pm.counts, 2));
         HIPCHK(hipHostMalloc((void**)&h->h_pm_out, (nt * (MAX_DTHETA + 2) + 1) * 8, hipHostMallocDefault));
     }
     h->pm_spec = sp;
@@ -738,18 +747,20 @@ extern "C" int smc_pmmh_rejuvenate(smc_handle h, smc_handle main, const double* 
         if ((rc = emit_if_needed(main))) return rc;
         HIPCHK(hipStreamSynchronize(main->stream));
     }
-    std::vector<double> th8((size_t)nt * MAX_DTHETA, 0.0), L8((size_t)MAX_DTHETA * MAX_DTHETA, 0.0);
-    for (int m = 0; m < nt; ++m)
-        for (int i = 0; i < d; ++i) th8[(size_t)m * MAX_DTHETA + i] = theta[(size_t)m * d + i];
-    for (int i = 0; i < d * d; ++i) L8[i] = chol[i];
+    {   // theta (rows padded to MAX_DTHETA), logZ, the Cholesky factor and the zeros of nrun / counts / any: one pinned block, one copy
+        // (the previous call's copy has completed: every call ends with a stream synchronisation)
+        double* in = h->h_pm_in;
+        memset(in, 0, h->pm_in_words * 8);
+        for (int m = 0; m < nt; ++m)
+            for (int i = 0; i < d; ++i) in[(size_t)m * MAX_DTHETA + i] = theta[(size_t)m * d + i];
+        double* in_logZ = in + (size_t)nt * MAX_DTHETA;
+        memcpy(in_logZ, logZ, (size_t)nt * 8);
+        double* in_chol = in_logZ + nt;
+        for (int i = 0; i < d * d; ++i) in_chol[i] = chol[i];
+    }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->pm.theta, th8.data(), th8.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->pm.logZ, logZ, (size_t)nt * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->pm.chol, L8.data(), L8.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->pm.any, 0, (size_t)nt, h->stream));
-    HIPCHK(hipMemsetAsync(h->pm.nrun, 0, 8, h->stream));
-    HIPCHK(hipMemsetAsync(h->pm.counts, 0, 8, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pm_in, h->h_pm_in, h->pm_in_words * 8, hipMemcpyHostToDevice, h->stream));
     const dim3 grid((unsigned)((nt + 127) / 128)), block(128);
     for (int c = 0; c < chain; ++c) {
         hipLaunchKernelGGL(k_pmmh_propose, grid, block, 0, h->stream, h->v, sp, h->pm, h->model, move_seed, (uint32_t)c,
