@@ -505,25 +505,41 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
     // (lw_alive: |k| < 2^30), so that k - kb never wraps: nothing after the maximum has to ask again who is alive
     constexpr int DEAD = -(1 << 30);
     double p[NP][2];
+    double kq[NP][2];
     int kk[NP][2];
     int kloc = DEAD;
+    // the exponents first (two instructions each): their maximum is a chain of cross-lane steps, an LDS round trip and a
+    // barrier - started here, it runs under the polynomials instead of behind them
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const double l = lw[k][j];
-            const bool alive = lw_alive(l);
-            double kq;
-            const double pe = sp_exp_parts(l, kq);   // garbage for a dead particle: dropped here
-            p[k][j] = alive ? pe : 0.0;
-            // keep the polynomial HERE (the compiler otherwise sinks it behind the barrier into
-            // divergent per-particle branches and re-materialises its constants in each of them)
-            asm volatile("" : "+v"(p[k][j]));
-            kk[k][j] = alive ? (int)kq : DEAD;
+            kq[k][j] = sp_exp_k(l);
+            kk[k][j] = lw_alive(l) ? (int)kq[k][j] : DEAD;
             kloc = kk[k][j] > kloc ? kk[k][j] : kloc;
         }
     }
-    const int kbi = block_max_i32<THREADS>(kloc, (int*)scr);
+    {
+        const int wm = wave_max_i32(kloc);
+        if (lane == 0) ((int*)scr)[wave] = wm;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double l = lw[k][j];
+            const double pe = sp_exp_p(l, kq[k][j]);   // garbage for a dead particle: dropped here
+            p[k][j] = lw_alive(l) ? pe : 0.0;
+            // keep the polynomial HERE (the compiler otherwise sinks it behind the barrier into
+            // divergent per-particle branches and re-materialises its constants in each of them)
+            asm volatile("" : "+v"(p[k][j]));
+        }
+    }
+    __syncthreads();
+    int kbi = ((int*)scr)[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) kbi = ((int*)scr)[w] > kbi ? ((int*)scr)[w] : kbi;
     const double kb = kbi == DEAD ? -inf() : (double)kbi;
 
     uint64_t q[NP][2], ps[NP], incl[NP];

@@ -175,8 +175,15 @@ inline double sqrt_moderate_or_negzero(double x) { return sqrt(x); }
 
 // ---- exp / log / sincos ----------------------------------------------------------------
 // exp(x) = p * 2^k, k = rint(x / ln2) returned as an integral double, p in [0.707, 1.415]; |x| <= 7e8
+// the two halves of sp_exp_parts: k alone (two instructions), and p once k is known
+SMC_HD double sp_exp_k(double x) { return rne(x * INV_LN2); }
+SMC_HD double sp_exp_p(double x, double k);
 SMC_HD double sp_exp_parts(double x, double& kout) {
-    const double k = rne(x * INV_LN2);
+    const double k = sp_exp_k(x);
+    kout = k;
+    return sp_exp_p(x, k);
+}
+SMC_HD double sp_exp_p(double x, double k) {
     double r = fma(-k, LN2_HI, x);
     r = fma(-k, LN2_LO, r);
     double p = 0x1.6124613a86d09p-33;
@@ -193,7 +200,6 @@ SMC_HD double sp_exp_parts(double x, double& kout) {
     p = SMC_FMAK(p, r, 0.5);
     p = SMC_FMAK(p, r, 1.0);
     p = SMC_FMAK(p, r, 1.0);
-    kout = k;
     return p;
 }
 
