@@ -2,6 +2,8 @@
 header declares, its host build of the numerical spec equals the oracle bit for bit, and the
 entry points fail loudly (never fall back) without a GPU."""
 import ctypes as C
+import json
+import sys
 import os
 import re
 
@@ -226,6 +228,43 @@ def test_host_reweight_is_normalize(L):
     om2, lz2, ess2, j2 = L.host_outer_steps(omega0, logZ0, lik, ess_min=thr + 1e-9)
     first = int(np.argmax(ess < thr + 1e-9)) + 1
     assert j2 == first and np.array_equal(ess2, ess[:first]) and np.array_equal(bits(lz2), bits(logZ0 + lik[:first].sum(axis=0))) or j2 == first
+
+
+_HV_SNIPPET = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from sequential_monte_carlo_amd import _lib as L
+rng = np.random.default_rng(11)
+out = []
+for n in (1, 7, 64, 515, 4096):
+    om = rng.random(n); om[0] = 0.0
+    if n > 8: om[3] = 5e-320; om[5] = 2.3e-308
+    om /= om.sum()
+    lz = rng.normal(size=n)
+    lik = rng.normal(size=(5, n)) * 2.0
+    if n > 8: lik[1, 2] = -np.inf; lik[2, 4] = -900.0; lik[3, 6] = 710.0
+    o, z, e, j = L.host_outer_steps(om, lz, lik, 0.0)
+    lw = rng.normal(size=n) * 40; lw[n // 2] = -np.inf
+    lm, w, es = L.host_reweight(lw)
+    out.append([o.view(np.uint64).tolist(), z.view(np.uint64).tolist(), e.view(np.uint64).tolist(), int(j),
+                float(lm).hex(), np.asarray(w).view(np.uint64).tolist(), float(es).hex()])
+print(json.dumps(out))
+"""
+
+
+def test_host_vector_path_equals_scalar_path():
+    """The outer reweight's elementwise halves run as 4-wide vector code on hosts with AVX2 + FMA (smc_capi.hip, hv_*);
+    SMC_HOST_SCALAR=1 forces the scalar sp_log / sp_exp calls: the same bits, weights of zero, subnormal weights, -inf and
+    far-apart log-weights and lengths that are no multiple of the vector width included."""
+    import subprocess
+    code = _HV_SNIPPET % ROOT
+    runs = []
+    for env_extra in ({}, {"SMC_HOST_SCALAR": "1"}):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert runs[0] == runs[1]
 
 
 def test_exchange_plan_c_equals_python_and_is_consistent(L):
