@@ -133,6 +133,11 @@ int smc_host_reweight(const double* logw, int64_t n, double* w /*[n]*/, double* 
  * after step j, and the walk stops after the first step with ess < ess_min; *j_out = number of steps done. */
 int smc_host_outer_steps(double* omega /*[n]*/, double* logZ /*[n]*/, const double* lik /*[k][n]*/, int k, int64_t n,
                          double ess_min, double* ess_out /*[k]*/, int* j_out);
+/* the index draw of resample!(smc) (src/smc_samplers.jl:74-84: sample(1:n, Weights(w), m)) from m uniforms the caller drew and
+ * SORTED: a[i] = number of j with cdf_j <= u[i], cdf = running sums of w (left to right) divided by their total - the
+ * inverse-CDF lookup, ancestors in ascending order (0-based).  One linear merge: every rank of a multi-GPU run repeats it. */
+int smc_host_resample_sorted(const double* w, int64_t n, const double* u_sorted /*[m] ascending, in [0,1)*/, int64_t m,
+                             int32_t* a /*[m]*/);
 /* the spec's PMMH pieces on the host (parity tests): proposal, log prior (NaN-free; -inf outside the support) */
 int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
                           const double* chol, double scale, double* prop);

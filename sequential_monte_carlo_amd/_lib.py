@@ -24,7 +24,7 @@ EXPORTS = [
     "smc_set_skip", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_host_pmmh_propose", "smc_host_pmmh_log_uniform",
     "smc_host_prior_logpdf", "smc_step_window", "smc_step_commit",
     "smc_comm_unique_id", "smc_comm_create", "smc_comm_destroy", "smc_comm_rank", "smc_comm_all_gather", "smc_outer_reweight",
-    "smc_comm_exchange_slots", "smc_host_reweight", "smc_host_outer_steps", "smc_comm_plan_exchange",
+    "smc_comm_exchange_slots", "smc_host_reweight", "smc_host_outer_steps", "smc_comm_plan_exchange", "smc_host_resample_sorted",
 ]
 COMM_ID_BYTES = 128
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
@@ -127,6 +127,7 @@ def lib():
     L.smc_host_prior_logpdf.argtypes = [C.c_int, _dp, C.c_double]
     L.smc_host_reweight.argtypes = [_dp, C.c_int64, _dp, _dp, _dp]
     L.smc_host_outer_steps.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int64, C.c_double, _dp, _ip]
+    L.smc_host_resample_sorted.argtypes = [_dp, C.c_int64, _dp, C.c_int64, _i32p]
     L.smc_comm_unique_id.argtypes = [C.c_void_p]
     L.smc_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(h)]
     L.smc_comm_destroy.argtypes = [h]
@@ -224,6 +225,15 @@ def host_outer_steps(omega, logZ, lik, ess_min):
     j = C.c_int()
     check(lib().smc_host_outer_steps(_d(omega), _d(logZ), _d(lik), k, n, float(ess_min), _d(ess), C.byref(j)))
     return omega, logZ, ess[:j.value], j.value
+
+
+def host_resample_sorted(w, u_sorted):
+    """ancestors (ascending, 0-based) of the sorted uniforms u in the normalised running sums of w (smc_host_resample_sorted)"""
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    u = np.ascontiguousarray(u_sorted, dtype=np.float64)
+    a = np.empty(u.size, dtype=np.int32)
+    check(lib().smc_host_resample_sorted(_d(w), w.size, _d(u), u.size, a.ctypes.data_as(_i32p)))
+    return a
 
 
 def comm_unique_id():

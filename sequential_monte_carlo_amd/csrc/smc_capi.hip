@@ -1415,6 +1415,23 @@ extern "C" int smc_host_outer_steps(double* omega, double* logZ, const double* l
     return SMC_OK;
 }
 
+extern "C" int smc_host_resample_sorted(const double* w, int64_t n, const double* u, int64_t m, int32_t* a) {
+    if (!w || !u || !a || n <= 0 || m < 0) return fail(SMC_EINVAL, "smc_host_resample_sorted: bad argument");
+    std::vector<double> cdf((size_t)n);
+    double run = 0.0;
+    for (int64_t j = 0; j < n; ++j) { run = run + w[j]; cdf[(size_t)j] = run; }
+    const double tot = cdf[(size_t)n - 1];
+    if (!(tot > 0.0) || !finite_d(tot)) return fail(SMC_EINVAL, "smc_host_resample_sorted: the weights do not sum to a positive number");
+    for (int64_t j = 0; j < n; ++j) cdf[(size_t)j] = cdf[(size_t)j] / tot;
+    int64_t j = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        if (i > 0 && u[i] < u[i - 1]) return fail(SMC_EINVAL, "smc_host_resample_sorted: the uniforms are not sorted");
+        while (j < n && cdf[(size_t)j] <= u[i]) ++j;
+        a[i] = (int32_t)(j < n ? j : n - 1);
+    }
+    return SMC_OK;
+}
+
 extern "C" int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
                                      const double* chol, double scale, double* prop) {
     if (d_theta < 1 || d_theta > MAX_DTHETA || !theta || !chol || !prop) return fail(SMC_EINVAL, "smc_host_pmmh_propose: bad argument");

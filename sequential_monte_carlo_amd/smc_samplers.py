@@ -255,11 +255,13 @@ def estimated_trend(smc):
 def resample_(smc):
     """resample!(smc)   smc_samplers.jl:74-84 -- value-copy semantics."""
     w = smc.omega / smc.omega.sum()
-    a = smc.rng.choice(smc.M, size=smc.M, replace=True, p=w)     # iid multinomial (sample(1:M, Weights(w), M))
-    # The order of the resampled population carries no information (the reference's `sample` returns it unsorted); taken
-    # in ascending order slot m inherits from an ancestor close to m, so with theta sharded over GPUs most of the filter
-    # copies of the online sampler stay on their rank and only the drift of the offspring counts crosses the links.
-    a = np.sort(a)
+    # iid multinomial (sample(1:M, Weights(w), M)), the draws of rng.choice(M, size=M, p=w): M uniforms looked up in the
+    # normalised running sums of w (numpy's own method, side="right").  The order of the resampled population carries no
+    # information (the reference's `sample` returns it unsorted); taken in ascending order slot m inherits from an ancestor
+    # close to m, so with theta sharded over GPUs most of the filter copies of the online sampler stay on their rank and only
+    # the drift of the offspring counts crosses the links - and sorting the UNIFORMS first gives that order directly (the
+    # lookup is monotone), at a third of the cost of choice + sort (every rank repeats this on all M particles).
+    a = _lib.host_resample_sorted(w, np.sort(smc.rng.random(smc.M)))     # == searchsorted(cumsum(w) / sum, u, "right")
     smc.theta = smc.theta[a].copy()
     smc.omega = smc.omega[a].copy()
     smc.logZ = smc.logZ[a].copy()

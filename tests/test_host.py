@@ -267,6 +267,28 @@ def test_host_vector_path_equals_scalar_path():
     assert runs[0] == runs[1]
 
 
+def test_host_resample_sorted_is_numpy_choice_sorted(L):
+    """smc_host_resample_sorted == sort(Generator.choice(n, m, p=w)) for the same uniforms (numpy looks its uniforms up in
+    cumsum(p) / cumsum(p)[-1] with side="right"): the index draw of resample!(smc), smc_samplers.jl:74-84."""
+    for trial in range(60):
+        g = np.random.default_rng(trial)
+        n = int(g.integers(1, 700))
+        w = g.random(n) ** 6
+        if trial % 3 == 0:
+            w[g.integers(0, n, n // 3 + 1)] = 0.0
+        if w.sum() == 0.0:
+            w[-1] = 1.0
+        w = w / w.sum()
+        r1, r2 = np.random.default_rng(100 + trial), np.random.default_rng(100 + trial)
+        a = L.host_resample_sorted(w, np.sort(r1.random(n)))
+        assert a.dtype == np.int32 and np.array_equal(a, np.sort(r2.choice(n, size=n, replace=True, p=w)))
+        assert np.all(w[a] > 0)                                   # never an ancestor of weight zero
+    with pytest.raises(RuntimeError):
+        L.host_resample_sorted(np.array([0.5, 0.5]), np.array([0.7, 0.2]))      # not sorted
+    with pytest.raises(RuntimeError):
+        L.host_resample_sorted(np.zeros(4), np.array([0.1]))
+
+
 def test_exchange_plan_c_equals_python_and_is_consistent(L):
     """smc_comm_plan_exchange (the host arithmetic of the C-level all-to-all of filter slots) for worlds of 1..8 ranks:
     identical to the plan distributed.ThetaComm.exchange_slots derives, every rank's sends match the other ranks' receives,
