@@ -84,7 +84,8 @@ int smc_get_state(smc_handle h, double* x /*[d][n_theta][n_x]*/, double* w /*[n_
 /* accumulated log-likelihood so far and ESS of the current weights */
 int smc_get_logZ(smc_handle h, double* logZ /*[n_theta]*/, double* ess /*[n_theta] or NULL*/);
 /* resample!(smc) of the OUTER sampler (src/smc_samplers.jl:74-84): filter slot m <- slot a[m]
- * (value copy of x cloud, weights and logZ; stream ids stay with the slot). */
+ * (value copy of x cloud, weights and logZ; stream ids stay with the slot).  The indices are copied before the call returns;
+ * the device work is enqueued on the handle's stream and NOT waited for (every later call on the handle is ordered behind it). */
 int smc_permute(smc_handle h, const int32_t* a /*[n_theta]*/);
 /* PMMH accept step of rejuvenate! (src/smc_samplers.jl:129-136): for every m with mask[m] != 0 the
  * filter state of slot m (x cloud, weights, logZ) is overwritten by slot m of `src` (the proposal

@@ -63,6 +63,7 @@ struct smc_filter_s {
     bool pm_cfg = false;
     PmmhDev pm{};
     double* h_pm_out = nullptr;                // pinned mirror: theta [ntheta][d] | logZ [ntheta] | any [ntheta] | nrun
+    int32_t* h_perm = nullptr;                 // pinned copy of smc_permute's index vector (the call does not wait for the device)
     double* pm_in = nullptr;                   // ONE device block: pm.theta | pm.logZ | pm.chol | pm.nrun | pm.counts | pm.any -
     double* h_pm_in = nullptr;                 //   a rejuvenation call fills its pinned twin and uploads it in one copy
     size_t pm_in_words = 0;
@@ -379,6 +380,7 @@ extern "C" int smc_destroy(smc_handle h) {
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
     if (h->h_pm_in) (void)hipHostFree(h->h_pm_in);
+    if (h->h_perm) (void)hipHostFree(h->h_perm);
     (void)hipFree(h->d_skip); (void)hipFree(h->d_order);
     if (h->h_win) (void)hipHostFree(h->h_win);
     (void)hipFree(h->pm.order);
@@ -924,7 +926,12 @@ extern "C" int smc_permute(smc_handle h, const int32_t* a) {
     int rc = emit_if_needed(h);
     if (rc) return rc;
     const FilterView& v = h->v;
-    HIPCHK(hipMemcpyAsync(h->d_perm, a, (size_t)v.ntheta * 4, hipMemcpyHostToDevice, h->stream));
+    // The call returns without waiting for the device (whatever follows on this handle is ordered behind on its stream; the host
+    // goes on with the random-walk covariance meanwhile): the indices travel from a pinned copy the handle owns.
+    if (!h->h_perm) HIPCHK(hipHostMalloc((void**)&h->h_perm, (size_t)v.ntheta * 4, hipHostMallocDefault));
+    else HIPCHK(hipStreamSynchronize(h->stream));   // (a previous permutation's copy out of the same buffer has completed)
+    memcpy(h->h_perm, a, (size_t)v.ntheta * 4);
+    HIPCHK(hipMemcpyAsync(h->d_perm, h->h_perm, (size_t)v.ntheta * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_logZ_tmp, v.logZ, (size_t)v.ntheta * 8, hipMemcpyDeviceToDevice, h->stream));
     hipLaunchKernelGGL(k_permute, dim3((unsigned)((v.npad + 255) / 256), v.ntheta), dim3(256), 0, h->stream, v, h->cur, h->d,
                        h->d_perm, h->d_logZ_tmp);
@@ -934,7 +941,6 @@ extern "C" int smc_permute(smc_handle h, const int32_t* a) {
     HIPCHK(hipMemcpyAsync(h->d_logZ_tmp, v.logZ, (size_t)v.ntheta * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(do_finalize(h, 0, h->t - 1));
     HIPCHK(hipMemcpyAsync(v.logZ, h->d_logZ_tmp, (size_t)v.ntheta * 8, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
     return SMC_OK;
 }
 
