@@ -649,6 +649,9 @@ def test_randomized_configurations(L, ob):
             assert bits([logZ[th]])[0] == bits([z])[0], ctx
             assert same(lm[:, th], olm) and same(es[:, th], oes), ctx
             assert same(x[:, th], ox) and same(w[th], ow) and np.array_equal(a[th], oa), ctx
+        # the same series without traces: no sums of squares are accumulated on the way and (logmu) of every step comes from
+        # the totals of the window prologue (emit_from_totals) - the same logZ, bit for bit
+        assert same(h.log_likelihood(y), logZ), (it, model, n, seg, nth, T, systematic)
         h.close()
 
 
