@@ -137,6 +137,15 @@ function resample(w::Vector{Float64}, N::Int64, ::Val{:hip}; seed::UInt64=rand(U
     return Int.(a) .+ 1            # the C ABI is 0-based
 end
 
+# the index draw of resample!(smc) in ascending order from uniforms of the caller's generator (one linear merge on the host):
+# with theta sharded over GPUs the ascending order keeps most filter copies on their rank (hip_exchange! below)
+function resample_sorted(w::Vector{Float64}, N::Int64=length(w))
+    u = sort!(rand(N)); a = Vector{Int32}(undef, N)
+    GC.@preserve w u a smc_check(ccall((:smc_host_resample_sorted, LIBSMC), Cint,
+        (Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Int32}), w, length(w), u, N, a))
+    return Int.(a) .+ 1
+end
+
 # ---- smc_samplers.jl: the SMC container keeps theta / omega / logZ on the host; x and w live in `main` ----------------
 # A sampler whose model closure yields one of the GPU families carries two extra fields (or a side table keyed by the
 # SMC object): `main::HipFilter` (the online filters smc.x, smc.w) and `prop::HipFilter` (the proposal filters of
