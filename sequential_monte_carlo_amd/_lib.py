@@ -313,7 +313,10 @@ class Handle:
     def set_streams(self, streams):
         s = np.ascontiguousarray(streams, dtype=np.uint32)
         assert s.size == self.n_theta
+        if getattr(self, "_streams_set", None) is not None and np.array_equal(self._streams_set, s):
+            return                     # unchanged (the samplers hand over the same global indices at every round): no upload, no wait
         check(lib().smc_set_streams(self._h, s.ctypes.data_as(_u32p)))
+        self._streams_set = s.copy()
 
     def reseed(self, seed):
         check(lib().smc_reseed(self._h, seed))

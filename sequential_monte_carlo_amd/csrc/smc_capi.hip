@@ -64,6 +64,7 @@ struct smc_filter_s {
     PmmhDev pm{};
     double* h_pm_out = nullptr;                // pinned mirror: theta [ntheta][d] | logZ [ntheta] | any [ntheta] | nrun
     int32_t* h_perm = nullptr;                 // pinned copy of smc_permute's index vector (the call does not wait for the device)
+    Params* h_params = nullptr;                // pinned twin of d_params (smc_set_params does not wait either)
     double* pm_in = nullptr;                   // ONE device block: pm.theta | pm.logZ | pm.chol | pm.nrun | pm.counts | pm.any -
     double* h_pm_in = nullptr;                 //   a rejuvenation call fills its pinned twin and uploads it in one copy
     size_t pm_in_words = 0;
@@ -381,6 +382,7 @@ extern "C" int smc_destroy(smc_handle h) {
     if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
     if (h->h_pm_in) (void)hipHostFree(h->h_pm_in);
     if (h->h_perm) (void)hipHostFree(h->h_perm);
+    if (h->h_params) (void)hipHostFree(h->h_params);
     (void)hipFree(h->d_skip); (void)hipFree(h->d_order);
     if (h->h_win) (void)hipHostFree(h->h_win);
     (void)hipFree(h->pm.order);
@@ -402,13 +404,16 @@ extern "C" int smc_set_params(smc_handle h, const double* raw) {
     if (!h || !raw) return fail(SMC_EINVAL, "smc_set_params: NULL argument");
     HIPCHK(hipSetDevice(h->device));
     const int nraw = model_nraw_rt(h->model);
-    std::vector<Params> P((size_t)h->v.ntheta);
+    // the rows are derived into a pinned twin and copied from there: the call does not wait for the device (what follows on the
+    // handle is ordered behind the copy); a previous copy out of the twin has completed once the stream is idle
+    if (!h->h_params) HIPCHK(hipHostMalloc((void**)&h->h_params, (size_t)h->v.ntheta * sizeof(Params), hipHostMallocDefault));
+    else HIPCHK(hipStreamSynchronize(h->stream));
+    Params* P = h->h_params;
     for (int m = 0; m < h->v.ntheta; ++m) {
         for (int k = 0; k < NPARAM; ++k) P[m].raw[k] = k < nraw ? raw[(size_t)m * nraw + k] : 0.0;
         derive_params(h->model, P[m].raw, P[m].der);
     }
-    HIPCHK(hipMemcpyAsync(h->d_params, P.data(), P.size() * sizeof(Params), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_params, P, (size_t)h->v.ntheta * sizeof(Params), hipMemcpyHostToDevice, h->stream));
     h->have_params = true;
     return SMC_OK;
 }
