@@ -237,11 +237,12 @@ import numpy as np, torch.distributed as dist
 import sequential_monte_carlo_amd as smc
 from sequential_monte_carlo_amd.distributed import ThetaComm
 from test_samplers_cpu import run_dt, run_online
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+WS = int(sys.argv[5])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=WS)
 for device in (False, True):      # host-loop rejuvenation / one-call-per-rank rejuvenation (ThetaMap)
     tag = sys.argv[4] + (".dev" if device else "")
     s, stages, text = run_dt(comm=ThetaComm(dist), device=device)
-    assert (s.lo, s.hi) == ((0, 16) if dist.get_rank() == 0 else (16, 32))
+    assert (s.lo, s.hi) == (dist.get_rank() * (32 // WS), (dist.get_rank() + 1) * (32 // WS))
     np.save(tag + ".%d.npy" % dist.get_rank(), np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]]))
     # online SMC^2 with theta sharded: resample! moves whole filters between the two ranks (all-to-all)
     so, moves, x, w = run_online(comm=ThetaComm(dist), device=device, window=5 if device else 0)
@@ -251,34 +252,37 @@ dist.destroy_process_group()
 '''
 
 
-def test_theta_sharding_world_size_2_gloo(tmp_path):
-    """N > 1 path: two gloo ranks each filter half of theta and all-gather logZ; the result is
-    identical on both ranks and identical to the single-process run (stream id = global theta index)."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_theta_sharding_world_size_2_gloo(tmp_path, world):
+    """N > 1 path: `world` gloo ranks each filter their share of theta and all-gather logZ; the result is
+    identical on every rank and identical to the single-process run (stream id = global theta index).  (Two and four
+    ranks: with four, resample! of the online sampler moves filters between ranks that are not neighbours.)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    port = str(29500 + (os.getpid() % 2000))
+    port = str(29500 + (os.getpid() % 2000) + world)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(tmp_path / "out")], env=env)
-             for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(tmp_path / "out"), str(world)], env=env)
+             for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     for device in (False, True):
         tag = str(tmp_path / "out") + (".dev" if device else "")
         s, stages, _ = run_dt(device=device)
         ref = np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]])
-        for r in range(2):
+        for r in range(world):
             got = np.load(tag + ".%d.npy" % r)
             assert np.array_equal(got, ref), device
-        # online SMC^2: the two halves of the filter states, concatenated, equal the single-process run
+        # online SMC^2: the ranks' shares of the filter states, concatenated, equal the single-process run
         so, moves, x, w = run_online(device=device)
         assert moves >= 1
         head = np.concatenate([so.theta.ravel(), so.logZ, so.omega])
-        parts = [np.load(tag + ".online.%d.npy" % r) for r in range(2)]
+        parts = [np.load(tag + ".online.%d.npy" % r) for r in range(world)]
         for p_ in parts:
             assert np.array_equal(p_[:head.size], head), device
         d, M, N = x.shape[0], x.shape[1], x.shape[2]
-        xs = np.concatenate([p_[head.size:head.size + d * (M // 2) * N].reshape(d, M // 2, N) for p_ in parts], axis=1)
-        ws = np.concatenate([p_[head.size + d * (M // 2) * N:].reshape(M // 2, N) for p_ in parts], axis=0)
+        per = M // world
+        xs = np.concatenate([p_[head.size:head.size + d * per * N].reshape(d, per, N) for p_ in parts], axis=1)
+        ws = np.concatenate([p_[head.size + d * per * N:].reshape(per, N) for p_ in parts], axis=0)
         assert np.array_equal(xs, x) and np.array_equal(ws, w), device
 
 
