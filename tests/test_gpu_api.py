@@ -1,11 +1,13 @@
 """GPU tests of the host mirror (particles.py, smc_samplers.py): the reference's API names over the
 HIP library, checked bit for bit against the same host logic running on the oracle backend."""
 import io
+import os
 
 import numpy as np
 import pytest
 
 import sequential_monte_carlo_amd as smc
+from conftest import ROOT
 from oracle_backend import OracleBackend
 from test_samplers_cpu import LG, LG_TMAP, lg_mod, lg_prior
 
@@ -559,3 +561,28 @@ def test_online_smc2_posterior_matches_density_tempered_and_exact():
     on, kf = np.array(on), np.array(kf)
     se = np.sqrt(on.var(axis=0, ddof=1) / len(on) + kf.var(axis=0, ddof=1) / len(kf))
     assert np.all(np.abs(on.mean(axis=0) - kf.mean(axis=0)) < 4.5 * se + 0.03), (on.mean(axis=0), kf.mean(axis=0), se)
+
+
+def test_bench_line_contract():
+    """`python bench.py` prints ONE JSON line with the driver's keys, `roofline` (live event brackets) and `cpu_baseline`
+    (the oracle on a bounded sample): run as the driver runs it, in a fresh process."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-aux"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "particle-steps/sec" and d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"] and d["value"] > 1e10
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 0.2 < r["frac"] < 1.0 and r["launch_ms"] > 0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 1e6 and "sample" in c
+
