@@ -836,10 +836,9 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
 
     ulonglong2 stg1[NP];   // single segment: the filter's whole C, staged like a multi-segment window of one
     constexpr bool EARLY1 = D == 1;   // (with three state coordinates the early copy only spills to scratch)
-    if (!MULTI && EARLY1) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) stg1[k] = reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS];
-    }
+    for (int k = 0; k < NP; ++k)   // (every element defined on every path: the array otherwise stays a stack object - 48 B of scratch)
+        stg1[k] = (!MULTI && EARLY1) ? reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS] : ulonglong2{0, 0};
 
     // ---- the state normals of this thread's children (under the loads of the records, the break points and the staged segments) ----------------
     double z[NP][D][2];
@@ -1035,8 +1034,8 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            if (!EARLY1) stg1[k] = reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS];
-            *reinterpret_cast<ulonglong2*>(Cst + lds_pad(2 * (tid + k * THREADS))) = stg1[k];
+            const ulonglong2 c2 = EARLY1 ? stg1[k] : reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS];
+            *reinterpret_cast<ulonglong2*>(Cst + lds_pad(2 * (tid + k * THREADS))) = c2;
         }
         __syncthreads();
     }
