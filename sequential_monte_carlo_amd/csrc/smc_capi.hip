@@ -94,7 +94,7 @@ bool geo_default(int seg, Geo& g) {
     switch (seg) {
     case 256: g = {128, 1}; return true;
     case 512: g = {256, 1}; return true;
-    case 1024: g = {256, 2}; return true;
+    case 1024: g = {512, 1}; return true;
     case 2048: g = {512, 2}; return true;
     case 4096: g = {512, 4}; return true;
     case 8192: g = {1024, 4}; return true;
@@ -104,11 +104,18 @@ bool geo_default(int seg, Geo& g) {
 }  // namespace smc
 
 extern "C" int smc_auto_seg(int64_t n) {
-    // measured (scripts/nx_sweep.py): 2048 up to 2^21 particles; beyond that the per-workgroup segment
-    // tables (16 B per segment in LDS) cost occupancy and 4096 wins; 8192 keeps nseg <= 4096 up to 2^25
+    // measured (scripts/nx_sweep.py, scripts/dbg/mid_sizes.py): one segment up to 2048 particles; above, the SHORTEST segment
+    // whose workgroup still has a thread per segment (nseg <= seg / 2 resp. 512: the one-record-per-thread table prologue) -
+    // a filter of 2^14..2^18 particles is a handful of workgroups on a 256-CU chip and bound by the life of ONE of them, which
+    // shorter segments (fewer particles per workgroup) cut from 9.4 to 6.0-7.3 us per step; 2048 up to 2^21 particles; beyond
+    // that the per-workgroup segment tables (16 B per segment in LDS) cost occupancy and 4096 wins; 8192 keeps nseg <= 4096 up
+    // to 2^25.  The segment length is part of the numerical spec (the CPU restatement used by the tests follows the same rule).
     if (n > ((int64_t)1 << 24)) return 8192;
     if (n > ((int64_t)1 << 21)) return 4096;
-    if (n > MAX_SEG) return 2048;
+    if (n > ((int64_t)1 << 19)) return 2048;
+    if (n > ((int64_t)1 << 17)) return 1024;
+    if (n > ((int64_t)1 << 15)) return 512;
+    if (n > MAX_SEG) return 256;
     int s = 256;
     while (s < n) s <<= 1;
     return s;
