@@ -450,7 +450,7 @@ def bench_sampler(args, ctx, algo, scaling, steps, warmup):
             calls = s._calls
             # `for t in 2:T smc²!(smc,y,t) end` (smc_samplers.jl:308-340), several propagation steps per device call
             smc.smc2_run(s, y, 2, T, window=args.window, verbose=False)
-            stages = [0] * ((s._calls - calls) // (chain + 1 if s.device_pmmh else chain))     # resample-move rounds
+            stages = [0] * ((s._calls - calls) // (chain + 2 if s.device_pmmh else chain + 1))     # resample-move rounds
         return s, stages
 
     for k in range(warmup):

@@ -125,20 +125,46 @@ int smc_pmmh_rejuvenate(smc_handle prop, smc_handle main /*or NULL*/, const doub
                         const double* chol /*[d_theta][d_theta]*/, const double* scales /*[chain]*/, int chain,
                         const uint64_t* filter_seeds /*[chain]*/, uint64_t move_seed, double* theta /*[n_theta][d_theta]*/,
                         double* logZ /*[n_theta]*/, uint8_t* accepted /*[n_theta] or NULL*/, int64_t* filters_run /*or NULL*/);
-/* reweight(logw) -> (logmu, w, ess) of the samplers (src/smc_samplers.jl:232,249,265,298,338; == normalize,
- * src/particles.jl:5-15) on the HOST in the spec's arithmetic (its exp / log, sums left to right): O(n_theta) outer work
- * that stays on the host as in the reference, with the same bits on every host and rank. */
-int smc_host_reweight(const double* logw, int64_t n, double* w /*[n]*/, double* logmu, double* ess);
+/* ---- the OUTER level of the samplers: one integer, order-free, shardable specification (host code, no GPU needed) --------
+ * reweight (undefined in the reference's tree; == normalize, src/particles.jl:5-15) is the inner filter's normalize with
+ * segments of SMC_OUTER_SEG consecutive entries: per segment the record (kb, S, S2hi, S2lo) = (largest binary exponent, sum
+ * and sum of squares of the 48-bit fixed-point weights relative to it), combined by shifts against the largest kb.  Integer
+ * sums only: the same bits for any order of evaluation and for any dealing of whole segments to ranks (a rank computes the
+ * records of the segments it holds, the ranks exchange records, every rank combines them).  The online sampler carries the
+ * UN-NORMALISED outer log-weights logw: smc²!'s `log.(omega) .+ lik` (:324) of re-normalised weights (:338) is the same
+ * weight vector up to a common factor, which reweight removes. */
+#define SMC_OUTER_SEG 8
+int smc_outer_seg(void);
+/* reweight(logw) -> (logmu, w, ess)   src/smc_samplers.jl:232,249,265,298,338; w [n] or NULL */
+int smc_host_reweight(const double* logw, int64_t n, double* w, double* logmu, double* ess);
+/* the records of the whole segments a rank holds (n_local entries beginning at a multiple of SMC_OUTER_SEG; the last segment
+ * of the whole vector may be short): rec [ceil(n_local / SMC_OUTER_SEG)][4] 8-byte words (bits of kb, S, S2hi, S2lo) */
+int smc_host_outer_records(const double* logw_local, int64_t n_local, uint64_t* rec);
+/* (logmu, ess) of a vector of n_total entries from the records of ALL its segments, in segment order */
+int smc_host_outer_combine(const uint64_t* rec, int64_t nseg, int64_t n_total, double* logmu, double* ess);
 /* the host half of up to k consecutive smc²! steps (src/smc_samplers.jl:323-338) over the log-likelihood increments
- * lik [k][n] of a window of inner-filter steps: omega and logZ are advanced in place step by step, ess_out[j] is the ESS
- * after step j, and the walk stops after the first step with ess < ess_min; *j_out = number of steps done. */
-int smc_host_outer_steps(double* omega /*[n]*/, double* logZ /*[n]*/, const double* lik /*[k][n]*/, int k, int64_t n,
-                         double ess_min, double* ess_out /*[k]*/, int* j_out);
-/* the index draw of resample!(smc) (src/smc_samplers.jl:74-84: sample(1:n, Weights(w), m)) from m uniforms the caller drew and
- * SORTED: a[i] = number of j with cdf_j <= u[i], cdf = running sums of w (left to right) divided by their total - the
- * inverse-CDF lookup, ancestors in ascending order (0-based).  One linear merge: every rank of a multi-GPU run repeats it. */
-int smc_host_resample_sorted(const double* w, int64_t n, const double* u_sorted /*[m] ascending, in [0,1)*/, int64_t m,
-                             int32_t* a /*[m]*/);
+ * lik [k][n_local] of a window of inner-filter steps, in three pieces so that only records cross the ranks:
+ *   smc_host_outer_window   records of logw + lik_1, logw + lik_1 + lik_2, ... (nothing modified): rec [k][nseg_local][4]
+ *   smc_host_outer_walk     ess of every step from the records of ALL segments, rec [k][nseg][4]; stops after the first step with
+ *                           ess < ess_min: *j_out = steps walked, ess_out [k]
+ *   smc_host_outer_advance  keep the first j steps: logw .+= lik_t, logZ .+= lik_t, t = 1..j in step order (:333-334) */
+int smc_host_outer_window(const double* logw_local, const double* lik /*[k][n_local]*/, int k, int64_t n_local, uint64_t* rec);
+int smc_host_outer_walk(const uint64_t* rec, int k, int64_t nseg, int64_t n_total, double ess_min, double* ess_out /*[k]*/, int* j_out);
+int smc_host_outer_advance(double* logw, double* logZ, const double* lik /*[k][n]*/, int j, int64_t n);
+/* the bisection for the next tempering exponent of density_tempered (src/smc_samplers.jl:240-266) in one call: *xi_new, the
+ * ESS of reweight((xi_new - xi) .* logZ), *resample_flag = 0 at the corner solution xi_new = 1 (:261-266); logw_out [n] or
+ * NULL = (xi_new - xi) .* logZ */
+int smc_host_outer_temper(const double* logZ, int64_t n, double xi, double ess_min, double* xi_new, double* ess, int* resample_flag,
+                          double* logw_out);
+/* the index draw of resample!(smc) (src/smc_samplers.jl:74-84: sample(1:n, Weights(w), m)) for the weights exp(logw): m iid
+ * draws through the inverse of the integer weight CDF, pick numbers = 64-bit Philox draws keyed by `seed`; ancestors in ASCENDING
+ * order, 0-based (the order of a resampled population carries no information; ascending keeps most filter copies of a sharded
+ * online sampler on their rank).  All weights zero: the identity. */
+int smc_host_outer_resample(const double* logw, int64_t n, int64_t m, uint64_t seed, int32_t* a /*[m]*/);
+/* random_walk_kernel(theta) (src/smc_samplers.jl:87-101): lower Cholesky factor L [d][d] (row-major) of the PMMH proposal
+ * covariance 2.83^2/d cov(theta) + 1e-10 I (1e-2 I when norm(cov) < 1e-8) from the cloud theta [n][d], fixed order of
+ * operations; d = 1: L = [[2.83^2 var + 1e-10]] handed to Normal() as a standard deviation (:87-92), *univariate = 1 */
+int smc_host_rw_factor(const double* theta, int64_t n, int d, double* L /*[d][d]*/, int* univariate);
 /* the spec's PMMH pieces on the host (parity tests): proposal, log prior (NaN-free; -inf outside the support) */
 int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
                           const double* chol, double scale, double* prop);
@@ -158,8 +184,9 @@ int smc_unpack_slots(smc_handle h, const int32_t* idx, int64_t k, const void* de
  * whatever means the host has (a file, a socket, Julia's Distributed); every rank then calls smc_comm_create.  RCCL
  * (xGMI) underneath, opened with dlopen at the first call.  The collectives are the ones the samplers have:
  *   smc_outer_reweight       reweight(logZ) / reweight(logw) of src/smc_samplers.jl:232,249,265,298,338 with the
- *                            entries sharded over the ranks: one all-gather of the slices, then normalize() on every rank
- *                            (w_all, logmu, ess identical everywhere; logw_all [n_local*world] may be NULL)
+ *                            entries sharded over the ranks: the SAME function as smc_host_reweight on the concatenated
+ *                            vector, bit for bit, for any number of ranks.  w_all and logw_all NULL and n_local a multiple of
+ *                            SMC_OUTER_SEG: the ranks exchange segment records only; otherwise one all-gather of the slices
  *   smc_comm_all_gather      n doubles per rank -> [world][n] on every rank (theta / logZ / accepted after rejuvenate!)
  *   smc_comm_exchange_slots  resample!(smc) of the online sampler (src/smc_samplers.jl:74-84) when the filters of `h`
  *                            are sharded: a[m] is the GLOBAL ancestor of GLOBAL slot m (same vector on every rank, rank r
@@ -171,8 +198,8 @@ int smc_comm_create(const void* id, int rank, int world, int device, smc_comm* o
 int smc_comm_destroy(smc_comm c);
 int smc_comm_rank(smc_comm c, int* rank, int* world);
 int smc_comm_all_gather(smc_comm c, const double* local /*[n]*/, int64_t n, double* all /*[world][n]*/);
-int smc_outer_reweight(smc_comm c, const double* logw_local /*[n_local]*/, int64_t n_local, double* logw_all,
-                       double* w_all /*[n_local*world]*/, double* logmu, double* ess);
+int smc_outer_reweight(smc_comm c, const double* logw_local /*[n_local]*/, int64_t n_local, double* logw_all /*or NULL*/,
+                       double* w_all /*[n_local*world] or NULL*/, double* logmu, double* ess);
 int smc_comm_exchange_slots(smc_comm c, smc_handle h, const int32_t* a /*[M]*/, int64_t M);
 /* the plan smc_comm_exchange_slots follows, as pure host arithmetic (no GPU; tested on CPU against the Python twin):
  * send_idx [<= M] local slots to pack, grouped by destination rank (send_cnt [world], *n_send in total); dest_idx [M/world]

@@ -89,6 +89,11 @@ def lib():
         L.orc_pmmh_propose.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, _dp, _dp, C.c_double, _dp]
         L.orc_pmmh_log_uniform.restype = C.c_double
         L.orc_pmmh_log_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_outer_reweight.argtypes = [_dp, C.c_int64, _dp, _dp, _dp]
+        L.orc_outer_steps.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int64, C.c_double, _dp]
+        L.orc_outer_temper.argtypes = [_dp, C.c_int64, C.c_double, C.c_double, _dp, _dp, _dp]
+        L.orc_outer_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, _i64p]
+        L.orc_rw_factor.argtypes = [_dp, C.c_int64, C.c_int, _dp]
         _lib = L
     return _lib
 
@@ -298,3 +303,50 @@ def kalman_log_likelihood(raw, y, predict_first=False):
     out = np.zeros(3)
     lib().orc_kalman_log_likelihood(_d(raw), _d(y), y.size, int(predict_first), _d(out))
     return out[0], out[1], out[2]
+
+
+# ---- the outer level of the samplers (orc_outer_*: reweight, window walk, tempering bisection, resample!, random-walk factor) ----
+def outer_reweight(logw, want_w=True):
+    """reweight(logw) -> (logmu, w, ess)   smc_samplers.jl:232,249,265,298,338"""
+    logw = np.ascontiguousarray(logw, dtype=np.float64)
+    w = np.zeros_like(logw) if want_w else None
+    lm, ess = C.c_double(), C.c_double()
+    assert lib().orc_outer_reweight(_d(logw), logw.size, _d(w) if want_w else None, C.byref(lm), C.byref(ess)) == 0
+    return lm.value, w, ess.value
+
+
+def outer_steps(logw, logZ, lik, ess_min):
+    """up to k smc²! host halves (smc_samplers.jl:323-338): -> (logw, logZ, ess [j], j), stopping below ess_min"""
+    lik = np.ascontiguousarray(lik, dtype=np.float64)
+    k, n = lik.shape
+    logw = np.array(logw, dtype=np.float64, order="C")
+    logZ = np.array(logZ, dtype=np.float64, order="C")
+    ess = np.zeros(k)
+    j = lib().orc_outer_steps(_d(logw), _d(logZ), _d(lik), k, n, float(ess_min), _d(ess))
+    return logw, logZ, ess[:j], j
+
+
+def outer_temper(logZ, xi, ess_min):
+    """the bisection of density_tempered (smc_samplers.jl:240-266): -> (xi_new, ess, resample_flag, logw)"""
+    logZ = np.ascontiguousarray(logZ, dtype=np.float64)
+    lw = np.zeros_like(logZ)
+    nx, e = C.c_double(), C.c_double()
+    flag = lib().orc_outer_temper(_d(logZ), logZ.size, float(xi), float(ess_min), C.byref(nx), C.byref(e), _d(lw))
+    return nx.value, e.value, bool(flag), lw
+
+
+def outer_resample(logw, m, seed):
+    """a = resample(omega) of resample!(smc) (smc_samplers.jl:74-84), ascending, 0-based"""
+    logw = np.ascontiguousarray(logw, dtype=np.float64)
+    a = np.zeros(int(m), dtype=np.int64)
+    assert lib().orc_outer_resample(_d(logw), logw.size, int(m), int(seed), a.ctypes.data_as(_i64p)) == 0
+    return a
+
+
+def rw_factor(theta):
+    """random_walk_kernel(theta) (smc_samplers.jl:87-101): -> (L [d][d], univariate)"""
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    n, d = theta.shape
+    L = np.zeros((d, d))
+    uni = lib().orc_rw_factor(_d(theta), n, d, _d(L))
+    return L, bool(uni)

@@ -975,3 +975,150 @@ void orc_filter_moments(const orc_filter* f, double* mean, double* var) {
     }
     free(w);
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* The OUTER level of the samplers (src/smc_samplers.jl): reweight, the window walk of     */
+/* smc²!, the tempering bisection, resample!(smc), the random-walk factor.                 */
+/* `reweight` is undefined in the reference's tree; it is normalize (particles.jl:5-15).   */
+/* Specification: the filter's own segmented fixed-point normalize   */
+/* with segments of 8 consecutive entries - every sum an integer sum, so the result does   */
+/* not depend on how the entries are dealt out to ranks.  These are the straightforward    */
+/* whole-vector versions: the product computes the same numbers rank by rank.              */
+/* ------------------------------------------------------------------------------------ */
+#define ORC_OUTER_SEG 8
+#define OUTER_STREAM 0xFFFFFFFEu   /* Philox stream id of the outer level */
+#define SLOT_OUTER 34u             /* pick numbers of resample!(smc) */
+
+/* reweight(logw) -> (logmu, w, ess)   smc_samplers.jl:232,249,265,298,338 */
+int orc_outer_reweight(const double* logw, int64_t n, double* w, double* logmu, double* ess) {
+    if (n <= 0) return -1;
+    orc_weights W;
+    weights_alloc(&W, n, ORC_OUTER_SEG);
+    weights_normalize(&W, logw);
+    if (w) weights_dense(&W, w);
+    if (logmu) *logmu = W.logmu;
+    if (ess) *ess = W.ess;
+    weights_free(&W);
+    return 0;
+}
+
+/* the host half of k consecutive smc²! steps (smc_samplers.jl:323-338) with un-normalised outer log-weights:
+ * logw .+= lik_t; logZ .+= lik_t; ess_t = reweight(logw).ess - stopping after the first step with ess_t < ess_min.
+ * logw and logZ are advanced in place by the steps walked; returns their number. */
+int orc_outer_steps(double* logw, double* logZ, const double* lik /*[k][n]*/, int k, int64_t n, double ess_min, double* ess_out) {
+    int j = 0;
+    while (j < k) {
+        const double* l = lik + (size_t)j * (size_t)n;
+        for (int64_t i = 0; i < n; ++i) { logw[i] = logw[i] + l[i]; logZ[i] = logZ[i] + l[i]; }
+        double e = 0.0;
+        orc_outer_reweight(logw, n, NULL, NULL, &e);
+        ess_out[j++] = e;
+        if (e < ess_min) break;
+    }
+    return j;
+}
+
+/* the bisection of density_tempered for the next exponent   smc_samplers.jl:240-266 */
+int orc_outer_temper(const double* logZ, int64_t n, double xi, double ess_min, double* xi_new, double* ess_new, double* logw_out) {
+    double* lw = (double*)malloc(sizeof(double) * (size_t)n);
+    double lower = xi, upper = 2.0, newxi = xi, e = 0.0;
+    int resample_flag = 1;
+    while (upper - lower > 1.e-6) {                                   /* :245 */
+        newxi = (upper + lower) / 2.0;                                /* :246 */
+        for (int64_t i = 0; i < n; ++i) lw[i] = (newxi - xi) * logZ[i];
+        orc_outer_reweight(lw, n, NULL, NULL, &e);                    /* :249 */
+        if (e == ess_min) break;                                      /* :251 */
+        else if (e < ess_min) upper = newxi;                          /* :253 */
+        else lower = newxi;                                           /* :255 */
+    }
+    if (newxi >= 1.0) {                                               /* :261 corner solution */
+        resample_flag = 0;
+        newxi = 1.0;
+        for (int64_t i = 0; i < n; ++i) lw[i] = (newxi - xi) * logZ[i];
+        orc_outer_reweight(lw, n, NULL, NULL, &e);                    /* :265 */
+    }
+    for (int64_t i = 0; i < n; ++i) lw[i] = (newxi - xi) * logZ[i];
+    if (logw_out) memcpy(logw_out, lw, sizeof(double) * (size_t)n);
+    free(lw);
+    *xi_new = newxi;
+    *ess_new = e;
+    return resample_flag;
+}
+
+static int u64_cmp(const void* a, const void* b) {
+    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : x > y;
+}
+/* a = resample(omega) of resample!(smc)   smc_samplers.jl:74-84: m iid draws from the weights exp(logw), the ancestors in
+ * ascending order (0-based).  The m targets are drawn, SORTED, and looked up one after the other. */
+int orc_outer_resample(const double* logw, int64_t n, int64_t m, uint64_t seed, int64_t* a) {
+    if (n <= 0 || m < 0) return -1;
+    orc_weights W;
+    weights_alloc(&W, n, ORC_OUTER_SEG);
+    weights_normalize(&W, logw);
+    if (W.Dtot == 0) {
+        for (int64_t j = 0; j < m; ++j) a[j] = j < n ? j : n - 1;
+        weights_free(&W);
+        return 0;
+    }
+    uint64_t* T = (uint64_t*)malloc(8 * (size_t)(m > 0 ? m : 1));
+    uint64_t r[2];
+    for (int64_t j = 0; j < m; ++j) {
+        if (!(j & 1)) resample_pair(seed, j >> 1, OUTER_STREAM, 0, SLOT_OUTER, r);
+        T[j] = (uint64_t)(((u128)r[j & 1] * W.Dtot) >> 64);
+    }
+    qsort(T, (size_t)m, 8, u64_cmp);
+    for (int64_t j = 0; j < m; ++j) {
+        const int b = (int)upper_bound_u64(W.Dcum, W.nseg, T[j]);
+        const uint64_t T2 = T[j] - (b ? W.Dcum[b - 1] : 0);
+        const double dk = W.K - W.kb[b];
+        int sh = (dk >= 0.0 && dk < 64.0) ? (int)dk + W.SH : 64;
+        if (sh > 64) sh = 64;
+        const uint64_t thr = sh < 64 ? ((T2 + 1) << sh) - 1 : 0;
+        int64_t i = (int64_t)b * W.seg + upper_bound_u64(W.C + (size_t)b * W.seg, W.seg, thr);
+        a[j] = i < n ? i : n - 1;
+    }
+    free(T);
+    weights_free(&W);
+    return 0;
+}
+
+/* random_walk_kernel(theta)   smc_samplers.jl:87-101: lower Cholesky factor L [d][d] of the proposal covariance from the
+ * cloud theta [n][d]; returns 1 for univariate theta (L = [[sigma]], handed to Normal() as a standard deviation, :87-92) */
+int orc_rw_factor(const double* theta, int64_t n, int d, double* L) {
+    double mean[8], cov[8][8], Sg[8][8];
+    for (int i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (int64_t m = 0; m < n; ++m) s = s + theta[m * d + i];
+        mean[i] = s / (double)n;
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int64_t m = 0; m < n; ++m) s = s + (theta[m * d + i] - mean[i]) * (theta[m * d + j] - mean[j]);
+            cov[i][j] = s / (double)(n - 1);
+            cov[j][i] = cov[i][j];
+        }
+    double nrm2 = 0.0;
+    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) nrm2 = nrm2 + cov[i][j] * cov[i][j];
+    const int collapsed = sqrt(nrm2) < 1.e-8;                                   /* norm(cov(theta)) < 1.e-8 */
+    const double dth = 2.83 * 2.83;
+    if (d == 1) {
+        L[0] = collapsed ? 1.e-2 : dth * cov[0][0] + 1.e-10;                     /* :89 */
+        return 1;
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j)
+            Sg[i][j] = collapsed ? (i == j ? 1.e-2 : 0.0) : (dth / (double)d) * cov[i][j] + (i == j ? 1.e-10 : 0.0);   /* :97-98 */
+    /* Cholesky-Banachiewicz, row by row */
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) L[i * d + j] = 0.0;
+    for (int i = 0; i < d; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double s = Sg[i][j];
+            for (int k = 0; k < j; ++k) s = s - L[i * d + k] * L[j * d + k];
+            L[i * d + j] = (i == j) ? sqrt(s) : s / L[j * d + j];
+        }
+    }
+    return 0;
+}

@@ -26,9 +26,22 @@ def wrap(obj, name, label=None):
             d = acc.setdefault(label, [0, 0.0]); d[0] += 1; d[1] += time.perf_counter() - t0
     setattr(obj, name, g)
 
-wrap(S, "resample_"); wrap(S, "random_walk_factor"); wrap(S, "_sync_params"); wrap(S, "_rejuvenate_device"); wrap(S, "_reweight")
+wrap(S, "resample_"); wrap(S, "random_walk_factor"); wrap(S, "_sync_params"); wrap(S, "_rejuvenate_device")
 wrap(backend, "rejuvenate", "backend.rejuvenate (device, blocking)")
-wrap(_lib, "host_outer_steps")
+# the outer level (csrc/smc_outer.hip).  With theta sharded over G ranks: "window" (records of the rank's own slice) divides by G;
+# "walk", "temper", "resample" and "rw_factor" are what every rank repeats on all parameter particles
+wrap(_lib, "host_outer_window", "outer: window records (per-rank share)"); wrap(_lib, "host_outer_walk", "outer: walk (replicated)")
+wrap(_lib, "host_outer_advance", "outer: advance (per-rank share)")
+def timed(f, label):
+    def g(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return f(*a, **k)
+        finally:
+            d = acc.setdefault(label, [0, 0.0]); d[0] += 1; d[1] += time.perf_counter() - t0
+    return g
+for nm in ("temper", "resample", "rw_factor", "reweight"):
+    setattr(S.LibOuter, nm, staticmethod(timed(getattr(S.LibOuter, nm), "outer: %s (replicated)" % nm)))
 wrap(_lib.Handle, "step_window", "Handle.step_window (device, blocking)"); wrap(_lib.Handle, "step_commit"); wrap(_lib.Handle, "permute")
 wrap(_lib.Handle, "pmmh_rejuvenate", "Handle.pmmh_rejuvenate (C call)"); wrap(_lib.Handle, "set_params"); wrap(_lib.Handle, "set_streams")
 wrap(_lib.Handle, "log_likelihood", "Handle.log_likelihood")

@@ -20,4 +20,4 @@ for rep in range(3):
     t0 = time.perf_counter(); smc.density_tempered(s, y, verbose=False); dt = time.perf_counter() - t0
     s2 = smc.SMC(1024, 512, mod, prior, 3, 0.5, theta_map=tmap)
     t0 = time.perf_counter(); smc.smc2(s2, y); smc.smc2_run(s2, y, 2, len(y), verbose=False); d2 = time.perf_counter() - t0
-print("density_tempered %.1f ms, smc2 %.1f ms; posterior mean" % (dt * 1e3, d2 * 1e3), (s.theta * (s.omega / s.omega.sum())[:, None]).sum(axis=0))
+print("density_tempered %.1f ms, smc2 %.1f ms; posterior mean" % (dt * 1e3, d2 * 1e3), (s.theta * s.omega[:, None]).sum(axis=0))

@@ -24,7 +24,9 @@ EXPORTS = [
     "smc_set_skip", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_host_pmmh_propose", "smc_host_pmmh_log_uniform",
     "smc_host_prior_logpdf", "smc_step_window", "smc_step_commit",
     "smc_comm_unique_id", "smc_comm_create", "smc_comm_destroy", "smc_comm_rank", "smc_comm_all_gather", "smc_outer_reweight",
-    "smc_comm_exchange_slots", "smc_host_reweight", "smc_host_outer_steps", "smc_comm_plan_exchange", "smc_host_resample_sorted",
+    "smc_comm_exchange_slots", "smc_host_reweight", "smc_comm_plan_exchange",
+    "smc_outer_seg", "smc_host_outer_records", "smc_host_outer_combine", "smc_host_outer_window", "smc_host_outer_walk",
+    "smc_host_outer_advance", "smc_host_outer_temper", "smc_host_outer_resample", "smc_host_rw_factor",
 ]
 COMM_ID_BYTES = 128
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
@@ -126,8 +128,14 @@ def lib():
     L.smc_host_prior_logpdf.restype = C.c_double
     L.smc_host_prior_logpdf.argtypes = [C.c_int, _dp, C.c_double]
     L.smc_host_reweight.argtypes = [_dp, C.c_int64, _dp, _dp, _dp]
-    L.smc_host_outer_steps.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int64, C.c_double, _dp, _ip]
-    L.smc_host_resample_sorted.argtypes = [_dp, C.c_int64, _dp, C.c_int64, _i32p]
+    L.smc_host_outer_records.argtypes = [_dp, C.c_int64, _u64p]
+    L.smc_host_outer_combine.argtypes = [_u64p, C.c_int64, C.c_int64, _dp, _dp]
+    L.smc_host_outer_window.argtypes = [_dp, _dp, C.c_int, C.c_int64, _u64p]
+    L.smc_host_outer_walk.argtypes = [_u64p, C.c_int, C.c_int64, C.c_int64, C.c_double, _dp, _ip]
+    L.smc_host_outer_advance.argtypes = [_dp, _dp, _dp, C.c_int, C.c_int64]
+    L.smc_host_outer_temper.argtypes = [_dp, C.c_int64, C.c_double, C.c_double, _dp, _dp, _ip, _dp]
+    L.smc_host_outer_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, _i32p]
+    L.smc_host_rw_factor.argtypes = [_dp, C.c_int64, C.c_int, _dp, _ip]
     L.smc_comm_unique_id.argtypes = [C.c_void_p]
     L.smc_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(h)]
     L.smc_comm_destroy.argtypes = [h]
@@ -206,34 +214,90 @@ def device_math(which, a, b=None, device=0):
     return out
 
 
-def host_reweight(logw):
-    """reweight(logw) -> (logmu, w, ess) on the host in the spec's arithmetic (smc_host_reweight; no GPU needed)"""
+OUTER_SEG = 8     # SMC_OUTER_SEG: entries per segment of the outer level's integer normalisation
+
+
+def host_reweight(logw, want_w=True):
+    """reweight(logw) -> (logmu, w, ess): the outer level's integer normalize (smc_host_reweight; no GPU needed)"""
     logw = np.ascontiguousarray(logw, dtype=np.float64)
-    w = np.empty_like(logw)
+    w = np.empty_like(logw) if want_w else None
     lm, ess = C.c_double(), C.c_double()
     check(lib().smc_host_reweight(_d(logw), logw.size, _d(w), C.byref(lm), C.byref(ess)))
     return lm.value, w, ess.value
 
 
-def host_outer_steps(omega, logZ, lik, ess_min):
-    """walk through the k steps of a window on the host (smc_host_outer_steps): -> (omega, logZ, ess [j], j)"""
+def host_outer_records(logw_local):
+    """segment records [nseg_local][4] (uint64 words) of the whole segments a rank holds (smc_host_outer_records)"""
+    lw = np.ascontiguousarray(logw_local, dtype=np.float64)
+    rec = np.zeros(((lw.size + OUTER_SEG - 1) // OUTER_SEG, 4), dtype=np.uint64)
+    check(lib().smc_host_outer_records(_d(lw), lw.size, rec.ctypes.data_as(_u64p)))
+    return rec
+
+
+def host_outer_combine(rec, n_total):
+    """(logmu, ess) from the records of ALL segments (smc_host_outer_combine)"""
+    rec = np.ascontiguousarray(rec, dtype=np.uint64).reshape(-1, 4)
+    lm, ess = C.c_double(), C.c_double()
+    check(lib().smc_host_outer_combine(rec.ctypes.data_as(_u64p), rec.shape[0], int(n_total), C.byref(lm), C.byref(ess)))
+    return lm.value, ess.value
+
+
+def host_outer_window(logw_local, lik):
+    """records [k][nseg_local][4] of the k steps of a window over this rank's entries (smc_host_outer_window)"""
+    lw = np.ascontiguousarray(logw_local, dtype=np.float64)
     lik = np.ascontiguousarray(lik, dtype=np.float64)
     k, n = lik.shape
-    omega = np.array(omega, dtype=np.float64, order="C")
-    logZ = np.array(logZ, dtype=np.float64, order="C")
+    assert n == lw.size
+    rec = np.zeros((k, (n + OUTER_SEG - 1) // OUTER_SEG, 4), dtype=np.uint64)
+    check(lib().smc_host_outer_window(_d(lw), _d(lik), k, n, rec.ctypes.data_as(_u64p)))
+    return rec
+
+
+def host_outer_walk(rec, n_total, ess_min):
+    """(ess [j], j): walk through the steps of a window from the records of ALL segments [k][nseg][4] (smc_host_outer_walk)"""
+    rec = np.ascontiguousarray(rec, dtype=np.uint64)
+    k, nseg = rec.shape[0], rec.shape[1]
     ess = np.zeros(k)
     j = C.c_int()
-    check(lib().smc_host_outer_steps(_d(omega), _d(logZ), _d(lik), k, n, float(ess_min), _d(ess), C.byref(j)))
-    return omega, logZ, ess[:j.value], j.value
+    check(lib().smc_host_outer_walk(rec.ctypes.data_as(_u64p), k, nseg, int(n_total), float(ess_min), _d(ess), C.byref(j)))
+    return ess[:j.value], j.value
 
 
-def host_resample_sorted(w, u_sorted):
-    """ancestors (ascending, 0-based) of the sorted uniforms u in the normalised running sums of w (smc_host_resample_sorted)"""
-    w = np.ascontiguousarray(w, dtype=np.float64)
-    u = np.ascontiguousarray(u_sorted, dtype=np.float64)
-    a = np.empty(u.size, dtype=np.int32)
-    check(lib().smc_host_resample_sorted(_d(w), w.size, _d(u), u.size, a.ctypes.data_as(_i32p)))
+def host_outer_advance(logw, logZ, lik, j):
+    """keep the first j steps of a window: (logw, logZ) advanced (new arrays)   (smc_host_outer_advance)"""
+    lik = np.ascontiguousarray(lik, dtype=np.float64)
+    logw = np.array(logw, dtype=np.float64, order="C")
+    logZ = np.array(logZ, dtype=np.float64, order="C")
+    assert lik.shape[1] == logw.size == logZ.size and 0 <= j <= lik.shape[0]
+    check(lib().smc_host_outer_advance(_d(logw), _d(logZ), _d(lik), int(j), logw.size))
+    return logw, logZ
+
+
+def host_outer_temper(logZ, xi, ess_min):
+    """the tempering bisection (smc_samplers.jl:240-266): -> (xi_new, ess, resample_flag, logw)   (smc_host_outer_temper)"""
+    logZ = np.ascontiguousarray(logZ, dtype=np.float64)
+    lw = np.empty_like(logZ)
+    nx, e, flag = C.c_double(), C.c_double(), C.c_int()
+    check(lib().smc_host_outer_temper(_d(logZ), logZ.size, float(xi), float(ess_min), C.byref(nx), C.byref(e), C.byref(flag), _d(lw)))
+    return nx.value, e.value, bool(flag.value), lw
+
+
+def host_outer_resample(logw, m, seed):
+    """ancestors (ascending, 0-based) of m iid draws from the weights exp(logw)   (smc_host_outer_resample)"""
+    logw = np.ascontiguousarray(logw, dtype=np.float64)
+    a = np.empty(int(m), dtype=np.int32)
+    check(lib().smc_host_outer_resample(_d(logw), logw.size, int(m), int(seed), a.ctypes.data_as(_i32p)))
     return a
+
+
+def host_rw_factor(theta):
+    """(L [d][d], univariate) of random_walk_kernel(theta)   (smc_host_rw_factor)"""
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    n, d = theta.shape
+    L = np.zeros((d, d))
+    uni = C.c_int()
+    check(lib().smc_host_rw_factor(_d(theta), n, d, _d(L), C.byref(uni)))
+    return L, bool(uni.value)
 
 
 def comm_unique_id():
@@ -269,10 +333,11 @@ class Comm:
         check(lib().smc_comm_all_gather(self._c, _d(local), local.size, _d(out)))
         return out
 
-    def outer_reweight(self, logw_local):
-        """(logmu, w [n_local*world], ess, logw_all) of the sharded log-weights: reweight on every rank"""
+    def outer_reweight(self, logw_local, want_w=True):
+        """(logmu, w [n_local*world], ess, logw_all) of the sharded log-weights: smc_host_reweight of the concatenated vector,
+        bit for bit; want_w=False: (logmu, None, ess, None) - whole-segment slices then exchange segment records only"""
         lw = np.ascontiguousarray(logw_local, dtype=np.float64).ravel()
-        allw, w = np.zeros(lw.size * self.world), np.zeros(lw.size * self.world)
+        allw, w = (np.zeros(lw.size * self.world), np.zeros(lw.size * self.world)) if want_w else (None, None)
         lm, ess = C.c_double(), C.c_double()
         check(lib().smc_outer_reweight(self._c, _d(lw), lw.size, _d(allw), _d(w), C.byref(lm), C.byref(ess)))
         return lm.value, w, ess.value, allw

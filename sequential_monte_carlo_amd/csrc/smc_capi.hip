@@ -1276,179 +1276,8 @@ extern "C" void smc_host_box_muller(const uint32_t w[4], double* z0, double* z1)
     box_muller(u32x4{{w[0], w[1], w[2], w[3]}}, *z0, *z1);
 }
 
-// ---- the elementwise halves of the outer reweight, in a form the host compiler vectorises (AVX2 + FMA) -------------------------
-// The outer level (reweight, smc_samplers.jl:232-338) is O(n_theta) host work per step that EVERY rank of a multi-GPU run repeats
-// on all parameter particles; its cost is a log and an exp per particle and step.  hv_log_weight / hv_exp_nonpos perform, element
-// by element, exactly the operations of sp_log / sp_exp for the arguments that occur there (a normalised weight >= 0; a
-// log-weight minus the maximum: <= 0 or -inf) - without branches, with the int <-> double conversions done on the bits, so that a
-// loop over them compiles to 4-wide vector code.  The sums stay scalar and left to right: the bits do not change (SMC_HOST_SCALAR=1
-// forces the scalar calls, tests/test_host.py compares the two).
-static inline double hv_log_weight(double x) {
-    const bool tiny = x < 0x1p-1022;
-    const double xs = tiny ? x * 0x1p54 : x;
-    const uint64_t b = d2bits(xs);
-    const uint64_t mant = b & 0x000fffffffffffffULL;
-    const bool up = mant > (0x3ff6a09e667f3bcdULL & 0x000fffffffffffffULL);
-    const uint64_t eb = ((b >> 52) & 0x7ff) + (up ? 1u : 0u) + (tiny ? (uint64_t)(0x80000 - 1023 - 54) : (uint64_t)(0x80000 - 1023));   // e + 2^19 > 0
-    const double dk = bits2d(0x4330000000000000ULL + eb) - (0x1p52 + 0x1p19);   // (double)e, exactly
-    const double m = bits2d(mant | (up ? 0x3fe0000000000000ULL : 0x3ff0000000000000ULL));
-    const double f = m - 1.0;
-    const double q = f / (2.0 + f);
-    const double z = q * q;
-    double R = 0x1.642c8590b2164p-4;
-    R = fma(R, z, 0x1.8618618618618p-4);
-    R = fma(R, z, 0x1.af286bca1af28p-4);
-    R = fma(R, z, 0x1.e1e1e1e1e1e1ep-4);
-    R = fma(R, z, 0x1.1111111111111p-3);
-    R = fma(R, z, 0x1.3b13b13b13b14p-3);
-    R = fma(R, z, 0x1.745d1745d1746p-3);
-    R = fma(R, z, 0x1.c71c71c71c71cp-3);
-    R = fma(R, z, 0x1.2492492492492p-2);
-    R = fma(R, z, 0x1.999999999999ap-2);
-    R = fma(R, z, 0x1.5555555555555p-1);
-    R = R * z;
-    const double r = dk * LN2_HI - ((q * (f - R) - dk * LN2_LO) - f);
-    return x == 0.0 ? -inf() : r;
-}
-static inline double hv_exp_nonpos(double x) {   // x <= 0 or -inf
-    const bool in = x > -708.0;
-    const double xc = in ? x : -708.0;
-    const double k = (xc * INV_LN2 + 0x1.8p52) - 0x1.8p52;   // rne
-    double r = fma(-k, LN2_HI, xc);
-    r = fma(-k, LN2_LO, r);
-    double p = 0x1.6124613a86d09p-33;
-    p = fma(p, r, 0x1.1eed8eff8d898p-29);
-    p = fma(p, r, 0x1.ae64567f544e4p-26);
-    p = fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = fma(p, r, 0x1.71de3a556c734p-19);
-    p = fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = fma(p, r, 0x1.6c16c16c16c17p-10);
-    p = fma(p, r, 0x1.1111111111111p-7);
-    p = fma(p, r, 0x1.5555555555555p-5);
-    p = fma(p, r, 0x1.5555555555555p-3);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    const uint64_t kb = d2bits((k + 1023.0) + 0x1p52) & 0x7ffULL;   // k + 1023 in [1, 1023]
-    const double v = p * bits2d(kb << 52);
-    return in ? v : 0.0;
-}
-#if defined(__x86_64__)
-#define SMC_HOSTVEC __attribute__((target("avx2,fma")))
-static bool host_vec_ok() {
-    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma") && !getenv("SMC_HOST_SCALAR");
-    return ok;
-}
-#else
-#define SMC_HOSTVEC
-static bool host_vec_ok() { return false; }
-#endif
-SMC_HOSTVEC static bool hv_weights_ok(const double* w, int64_t n) {   // every weight a number in [0, 1e300]
-    int bad = 0;
-    for (int64_t i = 0; i < n; ++i) bad |= !(w[i] >= 0.0 && w[i] <= 1e300);
-    return !bad;
-}
-SMC_HOSTVEC static bool hv_no_nan(const double* x, int64_t n) {
-    int bad = 0;
-    for (int64_t i = 0; i < n; ++i) bad |= !(x[i] == x[i]);
-    return !bad;
-}
-SMC_HOSTVEC static void hv_logw(const double* omega, const double* l, double* logw, double* logZ, int64_t n) {
-    for (int64_t i = 0; i < n; ++i) {
-        logw[i] = hv_log_weight(omega[i]) + l[i];
-        logZ[i] = logZ[i] + l[i];
-    }
-}
-SMC_HOSTVEC static void hv_exp_shifted(const double* logw, double m, double* w, int64_t n) {
-    for (int64_t i = 0; i < n; ++i) w[i] = hv_exp_nonpos(logw[i] - m);
-}
-SMC_HOSTVEC static void hv_div(double* w, double s, int64_t n) {
-    for (int64_t i = 0; i < n; ++i) w[i] = w[i] / s;
-}
-SMC_HOSTVEC static double hv_max(const double* x, int64_t n) {   // the maximum of numbers does not depend on the order (no NaN: checked by the caller)
-    double m[8];
-    for (int c = 0; c < 8; ++c) m[c] = -inf();
-    int64_t i = 0;
-    for (; i + 8 <= n; i += 8)
-        for (int c = 0; c < 8; ++c) m[c] = x[i + c] > m[c] ? x[i + c] : m[c];
-    double r = -inf();
-    for (int c = 0; c < 8; ++c) r = m[c] > r ? m[c] : r;
-    for (; i < n; ++i) r = x[i] > r ? x[i] : r;
-    return r;
-}
-
-// reweight(logw) of the samplers (== normalize, particles.jl:5-15) on the HOST, in the spec's arithmetic: the outer level
-// is O(n_theta) work the reference leaves on the host too; with sp_exp / sp_log and left-to-right sums every
-// host (this binding, the Julia wrapper, any rank) gets the same bits.  Returns logmu; w [n] normalised; *ess = 1 / sum w^2.
-static double host_reweight(const double* logw, int64_t n, double* w, double* ess) {
-    const bool vec = host_vec_ok() && hv_no_nan(logw, n);
-    double m = -inf();
-    if (vec) m = hv_max(logw, n);
-    else for (int64_t i = 0; i < n; ++i) m = logw[i] > m ? logw[i] : m;
-    if (!finite_d(m)) {
-        for (int64_t i = 0; i < n; ++i) w[i] = 1.0 / (double)n;
-        *ess = 0.0;
-        return -inf();
-    }
-    double s = 0.0, s2 = 0.0;
-    if (vec) {   // no NaN and m the maximum: every argument of the exp is <= 0 or -inf
-        hv_exp_shifted(logw, m, w, n);
-        for (int64_t i = 0; i < n; ++i) s = s + w[i];
-        hv_div(w, s, n);
-        for (int64_t i = 0; i < n; ++i) s2 = s2 + w[i] * w[i];
-    } else {
-        for (int64_t i = 0; i < n; ++i) { w[i] = sp_exp(logw[i] - m); s = s + w[i]; }
-        for (int64_t i = 0; i < n; ++i) { w[i] = w[i] / s; s2 = s2 + w[i] * w[i]; }
-    }
-    *ess = 1.0 / s2;
-    return (m + sp_log(s)) - sp_log((double)n);
-}
-extern "C" int smc_host_reweight(const double* logw, int64_t n, double* w, double* logmu, double* ess) {
-    if (!logw || !w || !logmu || !ess || n <= 0) return fail(SMC_EINVAL, "smc_host_reweight: bad argument");
-    *logmu = host_reweight(logw, n, w, ess);
-    return SMC_OK;
-}
-// The host half of up to k smc²! steps (smc_samplers.jl:323-338) over the log-likelihood increments lik [k][n] a window of
-// inner-filter steps returned: logω = log.(ω) .+ lik_j; logZ .+= lik_j; ω, ess = reweight(logω) - step by step, stopping
-// after the first step whose ESS falls below ess_min.  omega / logZ are updated in place; ess_out [k]; *j_out = steps done.
-extern "C" int smc_host_outer_steps(double* omega, double* logZ, const double* lik, int k, int64_t n, double ess_min,
-                                    double* ess_out, int* j_out) {
-    if (!omega || !logZ || !lik || !ess_out || !j_out || k < 1 || n <= 0) return fail(SMC_EINVAL, "smc_host_outer_steps: bad argument");
-    std::vector<double> logw((size_t)n);
-    int j = 0;
-    while (j < k) {
-        const double* l = lik + (size_t)j * (size_t)n;
-        if (host_vec_ok() && hv_weights_ok(omega, n)) {
-            hv_logw(omega, l, logw.data(), logZ, n);
-        } else {
-            for (int64_t i = 0; i < n; ++i) { logw[(size_t)i] = sp_log(omega[i]) + l[i]; logZ[i] = logZ[i] + l[i]; }
-        }
-        double ess;
-        (void)host_reweight(logw.data(), n, omega, &ess);
-        ess_out[j++] = ess;
-        if (ess < ess_min) break;
-    }
-    *j_out = j;
-    return SMC_OK;
-}
-
-extern "C" int smc_host_resample_sorted(const double* w, int64_t n, const double* u, int64_t m, int32_t* a) {
-    if (!w || !u || !a || n <= 0 || m < 0) return fail(SMC_EINVAL, "smc_host_resample_sorted: bad argument");
-    std::vector<double> cdf((size_t)n);
-    double run = 0.0;
-    for (int64_t j = 0; j < n; ++j) { run = run + w[j]; cdf[(size_t)j] = run; }
-    const double tot = cdf[(size_t)n - 1];
-    if (!(tot > 0.0) || !finite_d(tot)) return fail(SMC_EINVAL, "smc_host_resample_sorted: the weights do not sum to a positive number");
-    for (int64_t j = 0; j < n; ++j) cdf[(size_t)j] = cdf[(size_t)j] / tot;
-    int64_t j = 0;
-    for (int64_t i = 0; i < m; ++i) {
-        if (i > 0 && u[i] < u[i - 1]) return fail(SMC_EINVAL, "smc_host_resample_sorted: the uniforms are not sorted");
-        while (j < n && cdf[(size_t)j] <= u[i]) ++j;
-        a[i] = (int32_t)(j < n ? j : n - 1);
-    }
-    return SMC_OK;
-}
+// (the outer level of the samplers - reweight, the window walk, the tempering bisection, resample!, the random-walk factor -
+// lives in smc_outer.hip)
 
 extern "C" int smc_host_pmmh_propose(int d_theta, uint64_t move_seed, uint32_t stream, uint32_t c, const double* theta,
                                      const double* chol, double scale, double* prop) {

@@ -163,17 +163,30 @@ extern "C" int smc_comm_all_gather(smc_comm c, const double* local, int64_t n, d
     return SMC_OK;
 }
 
-// reweight(logw) with the entries of logw sharded over the ranks (smc_samplers.jl:232,249,265,298,338)
+// reweight(logw) with the entries of logw sharded over the ranks (smc_samplers.jl:232,249,265,298,338): smc_host_reweight of
+// the concatenated vector, bit for bit, whatever the number of ranks (the specification is a sum of integers over fixed
+// segments of SMC_OUTER_SEG entries: smc_outer.hip).  Slices made of whole segments and no weight vector asked for: only the
+// segment records travel (32 bytes per SMC_OUTER_SEG entries); otherwise the slices themselves.
 extern "C" int smc_outer_reweight(smc_comm c, const double* logw_local, int64_t n_local, double* logw_all, double* w_all,
                                   double* logmu, double* ess) {
-    if (!c || !logw_local || !w_all || n_local <= 0) return smc_set_error_(SMC_EINVAL, "smc_outer_reweight: bad argument");
+    if (!c || !logw_local || n_local <= 0) return smc_set_error_(SMC_EINVAL, "smc_outer_reweight: bad argument");
     const int64_t n = n_local * c->world;
+    if (!w_all && !logw_all && n_local % SMC_OUTER_SEG == 0) {
+        const int64_t ns = n_local / SMC_OUTER_SEG;
+        std::vector<uint64_t> mine((size_t)ns * 4), all((size_t)ns * 4 * (size_t)c->world);
+        int rc = smc_host_outer_records(logw_local, n_local, mine.data());
+        if (rc) return rc;
+        // the records travel as 8-byte words (no arithmetic touches them on the way)
+        rc = smc_comm_all_gather(c, reinterpret_cast<const double*>(mine.data()), ns * 4, reinterpret_cast<double*>(all.data()));
+        if (rc) return rc;
+        return smc_host_outer_combine(all.data(), ns * c->world, n, logmu, ess);
+    }
     std::vector<double> tmp;
     double* all = logw_all;
     if (!all) { tmp.resize((size_t)n); all = tmp.data(); }
     int rc = smc_comm_all_gather(c, logw_local, n_local, all);
     if (rc) return rc;
-    return smc_normalize(all, n, w_all, logmu, ess, c->device);   // the same integer-sum normalize on every rank
+    return smc_host_reweight(all, n, w_all, logmu, ess);
 }
 
 // Who sends which slot to whom (pure host arithmetic, exported so that it can be tested without GPUs).  What rank `rank`
@@ -229,15 +242,27 @@ extern "C" int smc_comm_exchange_slots(smc_comm c, smc_handle h, const int32_t* 
         c->xcap = need;
     }
     if (ns && (rc = smc_pack_slots(h, send_idx.data(), (int64_t)ns, c->d_xs))) return rc;   // synchronises the handle's stream
-    NCCLC(g_rccl.GroupStart());
-    size_t so = 0, ro = 0;
-    for (int r = 0; r < W; ++r) {
-        const size_t nsb = (size_t)send_cnt[(size_t)r] * (size_t)sb, nrb = (size_t)recv_cnt[(size_t)r] * (size_t)sb;
-        if (nsb) NCCLC(g_rccl.Send((const char*)c->d_xs + so, nsb, ncclUint8, r, c->comm, c->stream));
-        if (nrb) NCCLC(g_rccl.Recv((char*)c->d_xr + ro, nrb, ncclUint8, r, c->comm, c->stream));
-        so += nsb; ro += nrb;
+    // every Send / Recv sits between GroupStart and GroupEnd, and GroupEnd runs whatever happened in between: a group left open on
+    // this thread would swallow every later collective of the communicator (and the peers would wait for ever).  The first error
+    // is reported after the group has been closed; the filter slots of `h` are then undefined (some may have been received).
+    ncclResult_t first = g_rccl.GroupStart();
+    const char* where = "ncclGroupStart";
+    if (first == ncclSuccess) {
+        size_t so = 0, ro = 0;
+        for (int r = 0; r < W; ++r) {
+            const size_t nsb = (size_t)send_cnt[(size_t)r] * (size_t)sb, nrb = (size_t)recv_cnt[(size_t)r] * (size_t)sb;
+            if (nsb && first == ncclSuccess) { first = g_rccl.Send((const char*)c->d_xs + so, nsb, ncclUint8, r, c->comm, c->stream); where = "ncclSend"; }
+            if (nrb && first == ncclSuccess) { first = g_rccl.Recv((char*)c->d_xr + ro, nrb, ncclUint8, r, c->comm, c->stream); where = "ncclRecv"; }
+            so += nsb; ro += nrb;
+        }
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (first == ncclSuccess && end != ncclSuccess) { first = end; where = "ncclGroupEnd"; }
     }
-    NCCLC(g_rccl.GroupEnd());
+    if (first != ncclSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        return smc_set_error_(SMC_EHIP, (std::string("smc_comm_exchange_slots: ") + where + ": " + g_rccl.GetErrorString(first) +
+                                         " (the filter slots of the handle are undefined now)").c_str());
+    }
     HIPC(hipStreamSynchronize(c->stream));     // the unpack kernel runs on the handle's own stream
     if (nr && (rc = smc_unpack_slots(h, dest_idx.data(), (int64_t)nr, c->d_xr))) return rc;
     return SMC_OK;

@@ -2,9 +2,12 @@
 `for t in 2:T smc²!(smc,y,t) end` loop, several steps per device call), rejuvenate_, resample_, exchange!, and the
 summaries of plotting_utils.jl / the example script (estimated_trend, filtered_summaries).
 
-The O(n_theta) outer logic (bisection for the tempering exponent, resample!, the PMMH accept test,
-the random-walk kernel) stays on the host exactly as in the reference; every particle filter the
-reference runs inside `Threads.@threads for m in 1:M` (smc_samplers.jl:112-121,174-180,223-229) or
+The O(n_theta) outer logic (bisection for the tempering exponent, resample!, the random-walk kernel) stays on the host as in
+the reference, but its arithmetic is ONE specification shared by every host (csrc/smc_outer.hip, include/smc_hip.h "the OUTER
+level"): `reweight` is the inner filter's integer normalize over segments of 8 parameter particles, so its sums do not depend
+on the order of evaluation or on how theta is dealt out to ranks; the sampler carries the un-normalised outer log-weights
+`logw` (`omega` = their normalisation, on demand); resample! draws its indices from Philox through the integer weight CDF.
+Every particle filter the reference runs inside `Threads.@threads for m in 1:M` (smc_samplers.jl:112-121,174-180,223-229) or
 serially (:289-295,:325-335) becomes ONE batched call on the GPU (theta axis = workgroups).
 
 PMMH rejuvenation (rejuvenate!, smc_samplers.jl:103-146) runs entirely on the device when the sampler is given
@@ -15,13 +18,14 @@ overwrite of theta / logZ / x / w - with Philox draws keyed by the GLOBAL theta 
 With arbitrary Python closures / priors the same loop stays on the host (numpy random numbers) and only the filters
 are batched on the GPU.  Either way a proposal outside the prior's support is never filtered (:116).
 
-theta sharding (multi-GPU): pass `comm=ThetaComm(...)` (distributed.py).  Every rank holds the full
-(small) theta / logZ vectors and draws the same host random numbers from the same seed, so all ranks
-take identical decisions; a rank only *filters* its own contiguous slice of theta.  Collectives: one
-all-gather of the logZ slices per batched evaluation, one all-gather of the moved (theta, logZ, accepted) slices per
-rejuvenation, one all-gather of the log-likelihood increments per window of online steps, and one all-to-all of
-filter slots per resample! of the online sampler.  Results do not depend on the number of ranks: filter m always
-uses Philox stream id m.
+theta sharding (multi-GPU): pass `comm=ThetaComm(...)` (distributed.py).  A rank *filters* its own contiguous slice of theta
+and does the outer arithmetic of that slice; what every rank must agree on (the ESS of a step, the ancestors of a resample!,
+the random-walk factor) is computed from exchanged integers or from the same counter-based random numbers, so all ranks take
+identical decisions.  Collectives: one all-gather of the logZ slices per batched evaluation, one all-gather of the
+moved (theta, logZ, accepted) slices per rejuvenation, one all-gather of the SEGMENT RECORDS (32 bytes per 8 parameter
+particles and step) per window of online steps, one all-gather of the (logw, logZ) slices and one all-to-all of filter slots
+per resample! of the online sampler.  Results do not depend on the number of ranks: filter m always uses Philox stream id m,
+and the outer sums are integer sums over fixed segments.
 """
 import math
 import sys
@@ -66,8 +70,45 @@ class ThetaMap:
 
 
 # ---- filter backends ---------------------------------------------------------------------------
+class LibOuter:
+    """The outer level (reweight, window walk, tempering bisection, resample!, random-walk factor) by the library's host
+    routines (csrc/smc_outer.hip).  `window_walk` is where theta sharding shows: a rank whose slice consists of whole
+    segments computes the segment records of its own parameter particles and the ranks exchange records; otherwise the
+    log-likelihood increments are exchanged and every rank walks the whole vector - the same bits either way."""
+
+    reweight = staticmethod(_lib.host_reweight)
+    temper = staticmethod(_lib.host_outer_temper)
+    resample = staticmethod(_lib.host_outer_resample)
+    rw_factor = staticmethod(_lib.host_rw_factor)
+
+    def window_walk(self, smc, lik_local, ess_min):
+        """the host half of k = len(lik_local) smc²! steps (smc_samplers.jl:323-338): advances smc.logw / smc.logZ by the
+        steps walked and returns (ess [j], j)"""
+        lik_local = np.ascontiguousarray(lik_local, dtype=np.float64)
+        k, per = lik_local.shape
+        lo, hi = smc.lo, smc.hi
+        if smc.comm is None or (per % _lib.OUTER_SEG == 0):
+            rec = _lib.host_outer_window(smc.logw[lo:hi], lik_local)                  # [k][nseg_local][4]
+            if smc.comm is not None:
+                nsl = rec.shape[1]
+                allr = smc.comm.all_gather(rec.view(np.float64).ravel()).view(np.uint64)   # 8-byte words, no arithmetic on the way
+                rec = np.ascontiguousarray(allr.reshape(-1, k, nsl, 4).transpose(1, 0, 2, 3).reshape(k, -1, 4))
+            ess, j = _lib.host_outer_walk(rec, smc.M, ess_min)
+            smc.logw[lo:hi], smc.logZ[lo:hi] = _lib.host_outer_advance(smc.logw[lo:hi], smc.logZ[lo:hi], lik_local, j)
+            smc._outer_local = smc.comm is not None          # the other ranks' slices are stale until _sync_outer
+        else:
+            smc._sync_outer()
+            lik = smc._gather(lik_local.ravel()).reshape(-1, k, per).transpose(1, 0, 2).reshape(k, smc.M)
+            rec = _lib.host_outer_window(smc.logw, lik)
+            ess, j = _lib.host_outer_walk(rec, smc.M, ess_min)
+            smc.logw, smc.logZ = _lib.host_outer_advance(smc.logw, smc.logZ, lik, j)
+        return ess, j
+
+
 class HipBackend:
     """Runs the batched inner filters on one GPU through the C ABI (no CPU fallback)."""
+
+    outer = LibOuter()
 
     def __init__(self, device=0, seg=0, resampler="multinomial"):
         self.device, self.seg = device, seg
@@ -97,8 +138,10 @@ class HipBackend:
         h.set_params(raw)
         h.set_streams(streams)
         h.set_skip(skip if skip is not None and np.any(skip) else None)
-        out = h.log_likelihood(y)
-        h.set_skip(None)
+        try:
+            out = h.log_likelihood(y)
+        finally:
+            h.set_skip(None)     # whatever happened: the mask must not outlive this evaluation on the cached handle
         return out, h
 
     def rejuvenate(self, tmap, prior_spec, N, y, xi, chol, scales, filter_seeds, move_seed, streams, theta, logZ, main):
@@ -147,12 +190,14 @@ class SMC:
             self.theta = np.ascontiguousarray(prior.rand_many(self.rng, self.M), dtype=np.float64)
         else:
             self.theta = np.array([np.atleast_1d(prior.rand(self.rng)) for _ in range(self.M)], dtype=np.float64)
-        self.omega = np.full(self.M, 1.0 / self.M)
+        self.logw = np.zeros(self.M)        # un-normalised outer log-weights; omega = their normalisation (property)
         self.logZ = np.zeros(self.M)
         self.ess = float(self.M)
         self.ess_min = self.M * float(ess_threshold)
         self.acc_threshold, self.acc_ratio = float(min_ar), 0.0
         self.backend = backend if backend is not None else HipBackend()
+        self.outer = getattr(self.backend, "outer", None) or LibOuter()
+        self._outer_local = False           # True: only this rank's slice of logw / logZ is current (sharded online steps)
         self.prior_spec = prior.spec() if hasattr(prior, "spec") else None
         self.device_pmmh = (theta_map is not None and self.prior_spec is not None and hasattr(self.backend, "rejuvenate")
                             and self.theta.shape[1] == len(self.prior_spec[0]))
@@ -161,6 +206,7 @@ class SMC:
         self._calls = 0          # evaluation counter -> fresh Philox seed per batched evaluation
         self.psteps = 0          # executed inner particle-steps (all ranks), SURVEY 8(d)
         self.psteps_skipped = 0  # particle-steps of proposals outside the prior's support: never run (smc_samplers.jl:116)
+        self.psteps_speculated = 0   # particle-steps the windows of smc2_run ran beyond the kept ones (dropped steps + the re-run prefix)
         self._main = None        # device handle of the online filters (smc2)
         self._theta_dev = None   # (handle, theta slice) whose parameter rows are on the device
         self.t = 0
@@ -175,6 +221,28 @@ class SMC:
 
     def _gather(self, local):
         return local if self.comm is None else self.comm.all_gather(local)
+
+    def _sync_outer(self):
+        """after sharded online steps every rank has advanced only its own slice of logw / logZ: ONE all-gather brings the
+        full vectors up to date everywhere (before resample!, summaries, and when a public call returns)"""
+        if self._outer_local:
+            per = self.hi - self.lo
+            both = self._gather(np.concatenate([self.logw[self.lo:self.hi], self.logZ[self.lo:self.hi]])).reshape(-1, 2, per)
+            self.logw = np.ascontiguousarray(both[:, 0, :].ravel())
+            self.logZ = np.ascontiguousarray(both[:, 1, :].ravel())
+            self._outer_local = False
+
+    def _set_logw(self, logw):
+        """reweight(logw) (smc_samplers.jl:232,298): the sampler's outer weights become exp(logw), normalised"""
+        self.logw = np.array(logw, dtype=np.float64)
+        self._outer_local = False
+        _, _, self.ess = self.outer.reweight(self.logw, want_w=False)
+
+    @property
+    def omega(self):
+        """the normalised outer weights (the reference's smc.ω after reweight): reweight(logw)[1]"""
+        self._sync_outer()
+        return self.outer.reweight(self.logw)[1]
 
     def _models(self, thetas):
         """smc.model(theta[m]) for a block of parameter particles (objects, or parameter rows via raw_fn)."""
@@ -198,15 +266,9 @@ class SMC:
         return "ess     = %.3f\nmean(theta) = %s" % (self.ess, np.array2string(expected_parameters(self)))
 
 
-def _reweight(logw):
-    """reweight == normalize (particles.jl:5-15) on an n_theta-vector: O(n_theta) host work as in the reference, done by
-    the library's host routine in the spec's arithmetic (same bits on every host and rank; no GPU involved)."""
-    return _lib.host_reweight(logw)
-
-
 def expected_parameters(smc):
     """sum_m theta[m] * omega[m]   (smc_samplers.jl:61-65; omega normalised)"""
-    w = smc.omega / smc.omega.sum()
+    w = smc.omega
     return (smc.theta * w[:, None]).sum(axis=0)
 
 
@@ -222,19 +284,25 @@ def _per_theta(smc, local):
 def filtered_summaries(smc, p=(0.25, 0.5, 0.75), component=0):
     """(quantiles [len(p)], variance) of the filtered state of the online sampler, integrated over the parameter particles:
     per theta-particle the weighted quantiles and variance of its x cloud, then their omega-weighted means - what
-    get_quantiles_uc / get_quantiles_ucsv compute every period in examples/inflation_example.jl:39-55,239-252.
-    The per-filter summaries are computed on the device (smc_get_quantiles / smc_get_moments): no cloud leaves the GPU."""
+    get_quantiles_uc computes every period in examples/inflation_example.jl:39-55.
+    The per-filter summaries are computed on the device (smc_get_quantiles / smc_get_moments): no cloud leaves the GPU.
+    DEVIATIONS from the example, on purpose (parity unpinned: no reference fixture covers these numbers): (1) the example's
+    UCSV variant (:244-248) takes UNWEIGHTED quantile(x_cloud) / var(x_cloud) of the clouds and multiplies by the raw smc.ω;
+    here both variants use the w-weighted summaries of the UC variant and the normalised omega (right after rejuvenate! the
+    reference's ω is all ones: its sum is then M times the mean).  (2) The quantile is the inverse of the weighted empirical
+    CDF in the filter's integer weights (smc_get_quantiles), not StatsBase's interpolating definition (not vendored)."""
     if smc._main is None:
         raise ValueError("filtered_summaries needs the online sampler's filters (call smc2 first)")
     q = np.asarray(smc._main.quantiles(list(p), component))            # [M_local][len(p)]
     _, var = smc._main.moments()                                       # [d][M_local]
     allq = _per_theta(smc, np.column_stack([q, np.asarray(var)[component]]))
-    w = smc.omega / smc.omega.sum()
+    w = smc.omega
     return w @ allq[:, :-1], float(w @ allq[:, -1])
 
 
 def estimated_trend(smc):
-    """estimated_trend(smc)   src/plotting_utils.jl:116-124:  sum_m omega[m] * mean(observation(model(theta[m]), w[m]' x[m])).
+    """estimated_trend(smc)   src/plotting_utils.jl:116-124:  sum_m omega[m] * mean(observation(model(theta[m]), w[m]' x[m])),
+    with the NORMALISED omega (the reference uses smc.ω as it stands - all ones right after rejuvenate!; stated deviation).
     The filtered means w[m]' x[m] come from the device; mean(observation(.)) is B x for the linear model (ssm.jl:96-103),
     x[1] for UCSV (:244-247) and 0 for the stochastic-volatility model."""
     if smc._main is None:
@@ -248,22 +316,21 @@ def estimated_trend(smc):
     else:
         obs = np.zeros(rows.shape[0])
     allobs = _per_theta(smc, obs[:, None])[:, 0]
-    w = smc.omega / smc.omega.sum()
+    w = smc.omega
     return float(w @ allobs)
 
 
 def resample_(smc):
     """resample!(smc)   smc_samplers.jl:74-84 -- value-copy semantics."""
-    w = smc.omega / smc.omega.sum()
-    # iid multinomial (sample(1:M, Weights(w), M)), the draws of rng.choice(M, size=M, p=w): M uniforms looked up in the
-    # normalised running sums of w (numpy's own method, side="right").  The order of the resampled population carries no
-    # information (the reference's `sample` returns it unsorted); taken in ascending order slot m inherits from an ancestor
-    # close to m, so with theta sharded over GPUs most of the filter copies of the online sampler stay on their rank and only
-    # the drift of the offspring counts crosses the links - and sorting the UNIFORMS first gives that order directly (the
-    # lookup is monotone), at a third of the cost of choice + sort (every rank repeats this on all M particles).
-    a = _lib.host_resample_sorted(w, np.sort(smc.rng.random(smc.M)))     # == searchsorted(cumsum(w) / sum, u, "right")
+    smc._sync_outer()
+    # iid multinomial (sample(1:M, Weights(w), M)) through the integer CDF of the outer weights, pick numbers from Philox keyed
+    # by the evaluation counter (the same on every rank).  The order of the resampled population carries no information (the
+    # reference's `sample` returns it unsorted); taken in ascending order slot m inherits from an ancestor close to m, so with
+    # theta sharded over GPUs most of the filter copies of the online sampler stay on their rank and only the drift of the
+    # offspring counts crosses the links.
+    a = np.asarray(smc.outer.resample(smc.logw, smc.M, smc._next_seed()), dtype=np.int64)
     smc.theta = smc.theta[a].copy()
-    smc.omega = smc.omega[a].copy()
+    smc.logw = smc.logw[a].copy()
     smc.logZ = smc.logZ[a].copy()
     if smc._main is not None:
         if smc.comm is not None:
@@ -273,30 +340,23 @@ def resample_(smc):
     return a
 
 
-def random_walk_factor(theta, scales):
+def random_walk_factor(theta, scales, outer=None):
     """(L, s) such that the proposal of chain position c is  theta' = theta + sqrt(s[c]) * L z,  z ~ N(0, I):
     multivariate theta (smc_samplers.jl:95-100): MvNormal(x, scale * Sigma), Sigma = 2.83^2/d * cov(theta) + 1e-10 I
       (1e-2 I when the cloud has collapsed, norm(cov) < 1e-8)  ->  L = chol(Sigma), s = scales;
     univariate theta (:87-92): Normal(x, scale * sigma) with sigma = 2.83^2 * var(theta) + 1e-10 (1e-2 when collapsed)
-      handed over as the STANDARD DEVIATION  ->  L = [[sigma]], s = scales^2  (sqrt(s) = scale)."""
-    d = theta.shape[1]
+      handed over as the STANDARD DEVIATION  ->  L = [[sigma]], s = scales^2  (sqrt(s) = scale).
+    Covariance and factorisation in the library's fixed order of operations (smc_host_rw_factor): the same bits on every rank."""
     scales = np.asarray(scales, dtype=np.float64)
-    cov = np.atleast_2d(np.cov(theta.T))
-    if d == 1:
-        sigma = 1e-2 if np.linalg.norm(cov) < 1e-8 else 2.83 ** 2 * float(cov[0, 0]) + 1e-10
-        return np.array([[sigma]]), scales * scales
-    if np.linalg.norm(cov) < 1e-8:
-        sigma = 1e-2 * np.eye(d)
-    else:
-        sigma = (2.83 ** 2 / d) * cov + 1e-10 * np.eye(d)
-    return np.linalg.cholesky(sigma), scales
+    L, univariate = (outer or LibOuter).rw_factor(np.ascontiguousarray(theta, dtype=np.float64))
+    return L, (scales * scales if univariate else scales)
 
 
-def random_walk_kernel(theta):
+def random_walk_kernel(theta, outer=None):
     """random_walk_kernel(theta)   smc_samplers.jl:87-101
     returns f(x, scale, rng) -> a draw of the reference's Normal(x, scale*sigma) / MvNormal(x, scale*Sigma)."""
     d = theta.shape[1]
-    L, _ = random_walk_factor(theta, [1.0])            # fixed now: theta is updated in place during the chain
+    L, _ = random_walk_factor(theta, [1.0], outer)     # fixed now: theta is updated in place during the chain
 
     def eff(scale):
         return scale * scale if d == 1 else scale
@@ -324,7 +384,8 @@ def rejuvenate_(smc, y, xi=1.0, verbose=False, out=sys.stdout):
         accepted = _rejuvenate_device(smc, y, xi)
     else:
         accepted = _rejuvenate_host(smc, y, xi)
-    smc.omega = np.ones(smc.M)
+    smc.logw = np.zeros(smc.M)          # smc.ω = ones(M): the moved particles are equally weighted
+    smc._outer_local = False
     smc.acc_ratio = float(accepted.sum()) / smc.M
     if verbose:
         out.write("\tacc_rate: %1.5f" % smc.acc_ratio)
@@ -335,7 +396,7 @@ def _rejuvenate_device(smc, y, xi):
     """The whole `for m ... for c in 1:chain` loop (smc_samplers.jl:112-138) in one smc_pmmh_rejuvenate call per rank;
     the host contributes the random-walk factor (:95-100, from the full theta cloud every rank holds) and, with
     sharded theta, ONE all-gather of the moved (theta, logZ, accepted) slices afterwards."""
-    L, s = random_walk_factor(smc.theta, 0.5 * np.arange(smc.chain, 0, -1))     # 0.5*reverse(1:chain)
+    L, s = random_walk_factor(smc.theta, 0.5 * np.arange(smc.chain, 0, -1), smc.outer)     # 0.5*reverse(1:chain)
     seeds = np.array([smc._next_seed() for _ in range(smc.chain)], dtype=np.uint64)
     move_seed = smc._next_seed()
     lo, hi = smc.lo, smc.hi
@@ -355,7 +416,7 @@ def _rejuvenate_device(smc, y, xi):
 
 
 def _rejuvenate_host(smc, y, xi):
-    kernel = random_walk_kernel(smc.theta)
+    kernel = random_walk_kernel(smc.theta, smc.outer)
     scales = 0.5 * np.arange(smc.chain, 0, -1)          # 0.5*reverse(1:chain)
     accepted = np.zeros(smc.M, dtype=bool)
     many = hasattr(smc.prior, "logpdf_many")
@@ -389,27 +450,13 @@ def density_tempered(smc, y, verbose=True, out=sys.stdout):
     """density_tempered(smc, y)   smc_samplers.jl:222-281 (Duan & Fulop)."""
     y = np.asarray(y, dtype=np.float64)
     smc.logZ, _ = smc._filter_all(smc.theta, y)
-    _, smc.omega, smc.ess = _reweight(smc.logZ)
+    smc._set_logw(smc.logZ)                               # :232
     xi = 0.0
     stages = []
     while xi < 1.0:
-        resample_flag = True
-        lower, old, upper = xi, xi, 2.0
-        newxi = xi
-        while upper - lower > 1e-6:                       # bisection for the next exponent
-            newxi = (upper + lower) / 2.0
-            _, smc.omega, smc.ess = _reweight((newxi - old) * smc.logZ)
-            if smc.ess == smc.ess_min:
-                break
-            elif smc.ess < smc.ess_min:
-                upper = newxi
-            else:
-                lower = newxi
-        if newxi >= 1.0:                                  # corner solution
-            resample_flag = False
-            newxi = 1.0
-            _, smc.omega, smc.ess = _reweight((newxi - old) * smc.logZ)
-        xi = newxi
+        # the bisection for the next exponent (:240-258) and the corner solution (:261-266), one library call:
+        # ess == ess_min ends it, ess < ess_min lowers the upper end, else the lower end rises, until they are 1e-6 apart
+        xi, smc.ess, resample_flag, smc.logw = smc.outer.temper(smc.logZ, xi, smc.ess_min)
         if verbose:
             out.write("ξ = %1.5f\tess = %4.3f" % (xi, smc.ess))
         if resample_flag:
@@ -428,7 +475,7 @@ def smc2(smc, y):
     logmu, smc._main = smc.backend.init(models, smc.N, float(y[0]), smc._next_seed(), smc._streams(), key="main")
     smc.psteps += smc.M * smc.N
     smc.logZ = smc._gather(np.asarray(logmu, dtype=np.float64)).copy()
-    _, smc.omega, smc.ess = _reweight(smc.logZ)
+    smc._set_logw(smc.logZ)                               # :297-298
     smc.t = 1
     return smc
 
@@ -443,7 +490,9 @@ def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
         resample_(smc)
         rejuvenate_(smc, y[: t - 1], 1.0, verbose, out)
         _exchange(smc, y[: t - 1], verbose, out)
-    return _step_only(smc, y, t, verbose, out)
+    _step_only(smc, y, t, verbose, out)
+    smc._sync_outer()
+    return smc
 
 
 def smc2_run(smc, y, t_from, t_to, window=16, verbose=True, out=sys.stdout):
@@ -453,7 +502,7 @@ def smc2_run(smc, y, t_from, t_to, window=16, verbose=True, out=sys.stdout):
     clouds resident in LDS (smc_step_window), the host then walks through the window's outer ESS values exactly as
     smc²! would, and keeps the steps up to (and including) the first one whose ESS falls below the threshold
     (smc_step_commit; the speculated steps behind it are dropped and redone after the resample-move).
-    With sharded theta the window's log-likelihood increments are exchanged in one all-gather instead of one per step."""
+    With sharded theta a window costs ONE all-gather of segment records (LibOuter.window_walk) instead of one exchange per step."""
     y = np.asarray(y, dtype=np.float64)
     t = int(t_from)
     while t <= t_to:
@@ -474,18 +523,16 @@ def smc2_run(smc, y, t_from, t_to, window=16, verbose=True, out=sys.stdout):
                 continue
         _sync_params(smc)
         lik, _ = smc._main.step_window(y[t - 1: t - 1 + k])          # [k][M_local]
-        lik = np.asarray(lik, dtype=np.float64)
-        if smc.comm is not None:
-            per = smc.hi - smc.lo
-            lik = smc._gather(lik.ravel()).reshape(-1, k, per).transpose(1, 0, 2).reshape(k, smc.M)
-        smc.omega, smc.logZ, ess, j = _lib.host_outer_steps(smc.omega, smc.logZ, lik, smc.ess_min)
+        ess, j = smc.outer.window_walk(smc, np.asarray(lik, dtype=np.float64), smc.ess_min)
         smc.ess = float(ess[-1])
         smc.t = t + j - 1
         if verbose:
             out.write("\n" + "".join("t = %4d\tess = %4.3f\n" % (t + i, ess[i]) for i in range(j - 1)))
         smc._main.step_commit(j)
         smc.psteps += smc.M * smc.N * j
+        smc.psteps_speculated += smc.M * smc.N * ((k - j) + (j if j < k else 0))   # dropped steps + the prefix smc_step_commit re-runs
         t += j
+    smc._sync_outer()
     return smc
 
 
@@ -501,9 +548,8 @@ def _step_only(smc, y, t, verbose, out):
     """the propagation half of smc²! (smc_samplers.jl:323-338), without the degeneracy check"""
     _sync_params(smc)
     lik, _ = smc._main.step(float(y[t - 1]))
-    lik = smc._gather(np.asarray(lik, dtype=np.float64))
     smc.psteps += smc.M * smc.N
-    smc.omega, smc.logZ, ess, _ = _lib.host_outer_steps(smc.omega, smc.logZ, lik[None, :], 0.0)
+    ess, _ = smc.outer.window_walk(smc, np.asarray(lik, dtype=np.float64)[None, :], 0.0)
     smc.ess = float(ess[0])
     smc.t = t
     if verbose:
@@ -526,7 +572,8 @@ def _exchange(smc, y, verbose, out):
             smc._theta_dev = None
             if old is not None and old is not h and hasattr(smc.backend, "release"):
                 smc.backend.release(old)          # the superseded N-particle filters
-            _, smc.omega, smc.ess = _reweight(np.asarray(new_logZ) - smc.logZ)
+            smc._sync_outer()
+            smc._set_logw(np.asarray(new_logZ) - smc.logZ)          # :183
             smc.logZ = np.asarray(new_logZ, dtype=np.float64).copy()
         else:
             out.write("\n\t[cannot exceed max state particles]")

@@ -89,7 +89,32 @@ class OracleHandle:
         return np.stack([x[0] for x in xs], axis=1), np.stack([x[1] for x in xs]), None
 
 
+class OracleOuter:
+    """The outer level of the samplers (reweight, the window walk of smc²!, the tempering bisection, resample!, the
+    random-walk factor) by the oracle's whole-vector restatements (oracle/smc_oracle.c orc_outer_*, orc_rw_factor): the
+    independent twin of sequential_monte_carlo_amd.smc_samplers.LibOuter (csrc/smc_outer.hip, which works rank by rank on
+    segment records).  With theta sharded every rank here walks the WHOLE vector: the log-likelihood increments travel."""
+
+    @staticmethod
+    def reweight(logw, want_w=True):
+        return ob.outer_reweight(logw, want_w)
+
+    temper = staticmethod(ob.outer_temper)
+    resample = staticmethod(ob.outer_resample)
+    rw_factor = staticmethod(ob.rw_factor)
+
+    def window_walk(self, smc, lik_local, ess_min):
+        lik_local = np.ascontiguousarray(lik_local, dtype=np.float64)
+        k, per = lik_local.shape
+        smc._sync_outer()
+        lik = lik_local if smc.comm is None else smc._gather(lik_local.ravel()).reshape(-1, k, per).transpose(1, 0, 2).reshape(k, smc.M)
+        smc.logw, smc.logZ, ess, j = ob.outer_steps(smc.logw, smc.logZ, lik, ess_min)     # smc_samplers.jl:323-338
+        return ess, j
+
+
 class OracleBackend:
+    outer = OracleOuter()
+
     def __init__(self, seg=0, resampler="multinomial"):
         self.seg, self.systematic = seg, resampler == "systematic"
         self.filters_run = 0

@@ -358,7 +358,8 @@ def test_sharded_online_smc2_single_rank_rccl():
 
 def test_native_rccl_comm_single_rank(ob):
     """smc_comm_* (the samplers' collectives inside libsmchip.so over RCCL, for hosts without torch.distributed) with a
-    world of one rank: outer reweight == normalize, all-gather == identity, exchange_slots == smc_permute, and the whole
+    world of one rank: outer reweight == the reweight every sampler path uses (smc_host_reweight; by segment records too),
+    all-gather == identity, exchange_slots == smc_permute, and the whole
     online sampler through it equals the unsharded run.  (More ranks need more GPUs than the test box has: the rank
     arithmetic is the one distributed.ThetaComm runs in the world_size-2 gloo test.)"""
     from sequential_monte_carlo_amd import _lib as L
@@ -367,8 +368,12 @@ def test_native_rccl_comm_single_rank(ob):
         rng = np.random.default_rng(3)
         logw = rng.normal(size=512) * 3 - 700
         lm, w, ess, allw = c.outer_reweight(logw)
-        lm0, w0, ess0 = L.normalize(logw)
+        lm0, w0, ess0 = L.host_reweight(logw)
         assert np.array_equal(bits(allw), bits(logw)) and np.array_equal(bits(w), bits(w0)) and (lm, ess) == (lm0, ess0)
+        lm1, w1, ess1, _ = c.outer_reweight(logw, want_w=False)          # whole segments, no weights asked for: records travel
+        assert w1 is None and (lm1, ess1) == (lm0, ess0) == ob.outer_reweight(logw)[::2]
+        lm2, _, ess2, _ = c.outer_reweight(logw[:509], want_w=False)     # no whole segments: the slices travel
+        assert (lm2, ess2) == L.host_reweight(logw[:509])[::2]
         v = rng.normal(size=77)
         assert np.array_equal(bits(c.all_gather(v)), bits(v))
         m = smc.UnivariateLinearGaussian(**LG)
@@ -457,7 +462,7 @@ def test_full_size_samplers_c4_c5_properties():
     for s in (b, c):
         assert np.array_equal(bits(a.theta), bits(s.theta)) and np.array_equal(bits(a.logZ), bits(s.logZ)) and a.psteps == s.psteps
     assert a.device_pmmh and a.psteps_skipped > 0 and abs(a.omega.sum() - 1) < 1e-12 and 1 <= a.ess <= M
-    rounds = (a._calls - 1) // (chain + 1)
+    rounds = (a._calls - 1) // (chain + 2)          # per resample-move round: the resample draw, chain filter seeds, the move seed
     assert rounds >= 3 and a.psteps + a.psteps_skipped >= M * N * T
     th = smc.expected_parameters(a)
     assert abs(th[0] - 0.5) < 0.3 and 0.3 < th[1] < 2.0 and 0.3 < th[2] < 2.0          # simulated with (0.5, 0.9, 0.8)

@@ -159,14 +159,16 @@ JULIA_TO_C = {
     "Cint": {"int"}, "Int64": {"int64_t"}, "UInt64": {"uint64_t"}, "UInt32": {"uint32_t"}, "Float64": {"double"},
     "Cstring": {"char*"}, "Ptr{Cvoid}": {"smc_handle", "smc_comm", "void*"}, "Ref{Ptr{Cvoid}}": {"smc_handle*", "smc_comm*"},
     "Ptr{Float64}": {"double*"}, "Ptr{Int32}": {"int32_t*"}, "Ptr{UInt8}": {"uint8_t*"}, "Ptr{UInt64}": {"uint64_t*"},
-    "Ptr{Int64}": {"int64_t*"}, "Ptr{UInt32}": {"uint32_t*"},
+    "Ptr{Int64}": {"int64_t*"}, "Ptr{UInt32}": {"uint32_t*"}, "Ptr{Cint}": {"int*"},
 }
 
 
 def test_julia_binding_matches_header():
     """Julia cannot run in this image, so every `ccall((:name, LIBSMC), Ret, (ArgTypes...), ...)` of julia/hip_backend.jl
     is checked textually against include/smc_hip.h: the symbol exists, the return type, the arity and every argument
-    type agree; and types are defined before the first method that names them (the include-order bug of round 1)."""
+    type agree; types are defined before the first method that names them (the include-order bug of round 1); and the sampler
+    entry points are methods on the GPU-backed `HipSMC` with the REFERENCE's signatures (src/smc_samplers.jl:74,103,163,222,288,
+    308), so that existing callers reach them without a change at the call site."""
     src = open(os.path.join(ROOT, "julia", "hip_backend.jl")).read()
     sigs = _header_signatures()
     calls = re.findall(r"ccall\(\(:(\w+),\s*LIBSMC\),\s*([\w{}]+),\s*\(([^()]*)\)", src, flags=re.S)
@@ -182,52 +184,151 @@ def test_julia_binding_matches_header():
             assert c in JULIA_TO_C[j], (name, j, c)
         seen.add(name)
     # the entry points a sampler host needs are all bound
-    need = {"smc_create", "smc_destroy", "smc_set_params", "smc_init", "smc_step", "smc_log_likelihood", "smc_get_state",
+    need = {"smc_create", "smc_destroy", "smc_set_params", "smc_set_streams", "smc_init", "smc_step", "smc_log_likelihood", "smc_get_state",
             "smc_permute", "smc_pmmh_configure", "smc_pmmh_rejuvenate", "smc_step_window", "smc_step_commit", "smc_normalize",
             "smc_resample", "smc_get_quantiles", "smc_comm_unique_id", "smc_comm_create", "smc_outer_reweight",
-            "smc_comm_all_gather", "smc_comm_exchange_slots", "smc_last_error"}
+            "smc_comm_all_gather", "smc_comm_exchange_slots", "smc_last_error",
+            # the outer level: every host takes its numbers from the same library routines
+            "smc_host_reweight", "smc_host_outer_temper", "smc_host_outer_resample", "smc_host_rw_factor", "smc_host_outer_window",
+            "smc_host_outer_walk", "smc_host_outer_advance",
+            # priors / model closures outside the enumerated families: host-side proposals, skipped filters, accepted clouds copied
+            "smc_set_skip", "smc_copy_from"}
     assert need <= seen, need - seen
+    # the reference's sampler signatures, as methods on HipSMC (= SMC{SSM,XT,θT,HipKernel}: more specific than the reference's)
+    assert re.search(r"^const HipSMC\{SSM,XT,θT\} = SMC\{SSM,XT,θT,HipKernel\}", src, flags=re.M)
+    for sig in (r"function resample!\(smc::HipSMC\)",                                                              # :74
+                r"function rejuvenate!\(smc::HipSMC, y::Vector\{Float64\}, ξ::Float64, verbose::Bool\)",               # :103
+                r"rejuvenate!\(smc::HipSMC, y::Vector\{Float64\}, verbose::Bool\) = rejuvenate!\(smc, y, 1\.0, verbose\)",   # :148
+                r"function exchange!\(smc::HipSMC, y::Vector\{Float64\}, verbose::Bool\)",                            # :163
+                r"function density_tempered\(smc::HipSMC, y::Vector\{Float64\}, verbose=true\)",                      # :222
+                r"function smc²\(smc::HipSMC, y::Vector\{Float64\}\)",                                                # :288
+                r"function smc²!\(smc::HipSMC, y::Vector\{Float64\}, t::Int64, verbose::Bool=true\)",                 # :308
+                r"function expected_parameters\(smc::HipSMC\)",                                                      # :61
+                r"function HipSMC\(N::Int64, M::Int64, model::SSM, prior::Sampleable, chain::Int64, ess_threshold::Float64, min_ar::Float64=-1\.0;",
+                r"function SMC\(N::Int64, M::Int64, model::SSM, prior::Distributions\.Product, chain::Int64, ess_threshold::Float64,",
+                r"function HipSampler\(θ::Vector, model, prior;",
+                r"function Base\.getproperty\(smc::HipSMC, s::Symbol\)"):
+        assert re.search(sig, src), sig
+    # no method takes the extra positional sampler argument of round 2 any more
+    assert not re.search(r"\(smc::SMC, hs::HipSampler", src)
     # definition order: a struct is defined before any method signature or field names it
-    for ty in ("HipFilter", "HipParticles", "HipWeights", "HipSampler", "HipComm"):
+    for ty in ("HipFilter", "HipParticles", "HipWeights", "HipSampler", "HipComm", "HipKernel"):
         first_def = re.search(r"^(?:mutable )?struct %s\b" % ty, src, flags=re.M).start()
         uses = [m.start() for m in re.finditer(r"::%s\b" % ty, src)]
         assert uses and min(uses) > first_def, ty
+    assert min(m.start() for m in re.finditer(r"::HipSMC\b", src)) > src.index("const HipSMC{SSM,XT,θT}")
     # AbstractVector contract of the two views: size and getindex for both
     assert re.search(r"Base\.getindex\(p::HipParticles", src) and re.search(r"Base\.getindex\(w::HipWeights", src)
     assert re.search(r"Base\.size\(p::Union\{HipParticles,HipWeights\}\)", src)
 
 
-def test_host_reweight_is_normalize(L):
-    """smc_host_reweight == normalize (particles.jl:5-15): logmu = logsumexp(logw) - log n, w = softmax, ess = 1 / sum w^2;
-    smc_host_outer_steps == that many smc²! host halves one after the other, stopping below the ESS threshold."""
+def test_host_reweight_is_normalize(L, ob):
+    """smc_host_reweight == normalize (particles.jl:5-15): logmu = logsumexp(logw) - log n, w = softmax, ess = 1 / sum w^2 - and,
+    bit for bit, the oracle's whole-vector restatement (orc_outer_reweight); dead entries (-inf, NaN) carry no weight."""
     from scipy.special import logsumexp
     rng = np.random.default_rng(2)
-    for n in (1, 2, 17, 512, 4096):
+    for n in (1, 2, 7, 8, 9, 17, 512, 4096, 5000):
         logw = rng.normal(size=n) * 4 - 300
         lm, w, ess = L.host_reweight(logw)
         assert lm == pytest.approx(logsumexp(logw) - np.log(n), rel=1e-13) and abs(w.sum() - 1) < 1e-12
-        assert np.allclose(w, np.exp(logw - logsumexp(logw)), rtol=1e-12) and ess == pytest.approx(1 / np.sum(w * w), rel=1e-12)
+        assert np.allclose(w, np.exp(logw - logsumexp(logw)), rtol=1e-10, atol=1e-13) and ess == pytest.approx(1 / np.sum(w * w), rel=1e-10)   # 48-bit fixed point relative to the largest weight
+        olm, ow, oess = ob.outer_reweight(logw)
+        assert lm == olm and ess == oess and np.array_equal(bits(w), bits(ow))
+        lm2, w2, ess2 = L.host_reweight(logw, want_w=False)
+        assert w2 is None and (lm2, ess2) == (lm, ess)
     lm, w, ess = L.host_reweight(np.zeros(64))
     assert lm == 0.0 and ess == pytest.approx(64.0) and np.all(w == 1 / 64)
-    lm, w, ess = L.host_reweight(np.array([-np.inf, 0.0, -np.inf]))
+    lm, w, ess = L.host_reweight(np.array([-np.inf, 0.0, np.nan]))
     assert np.array_equal(w, [0.0, 1.0, 0.0]) and ess == 1.0 and lm == pytest.approx(-np.log(3))
     lm, w, ess = L.host_reweight(np.full(5, -np.inf))
-    assert lm == -np.inf and ess == 0.0 and np.all(w == 0.2)
-    M, k = 48, 6
-    lik = rng.normal(size=(k, M)) * 0.7 - 1.5
-    omega0, logZ0 = np.full(M, 1.0 / M), rng.normal(size=M)
-    om, lz, ess, j = L.host_outer_steps(omega0, logZ0, lik, ess_min=0.0)
-    assert j == k and ess.shape == (k,)
-    o, z = omega0.copy(), logZ0.copy()
-    for i in range(k):
-        _, o, e = L.host_reweight(np.array([L.lib().smc_host_log(float(v)) for v in o]) + lik[i])
-        z = z + lik[i]
-        assert e == ess[i]
-    assert np.array_equal(bits(o), bits(om)) and np.array_equal(bits(z), bits(lz))
-    thr = float(np.sort(ess)[2])                                   # stops after the first step below the threshold
-    om2, lz2, ess2, j2 = L.host_outer_steps(omega0, logZ0, lik, ess_min=thr + 1e-9)
-    first = int(np.argmax(ess < thr + 1e-9)) + 1
-    assert j2 == first and np.array_equal(ess2, ess[:first]) and np.array_equal(bits(lz2), bits(logZ0 + lik[:first].sum(axis=0))) or j2 == first
+    assert lm == -np.inf and ess == 0.0 and np.all(w == 0.0)
+    # far-apart log-weights: what lies 2^-48 below the largest weight of its segment, or 2^-64 below the largest segment, is 0
+    lw = np.array([0.0, -20.0, -30.0, -40.0] + [-1e3] * 8 + [-30.0])      # exp(-40) < 2^-48 < exp(-30)
+    lm, w, ess = L.host_reweight(lw)
+    assert w[0] > w[1] > w[2] > 0 and w[3] == 0 and np.all(w[4:12] == 0) and w[12] > 0
+    assert np.array_equal(bits(w), bits(ob.outer_reweight(lw)[1]))
+
+
+def test_outer_records_are_shardable(L, ob):
+    """The outer level's sums are integer sums over fixed segments of 8 entries: the records a rank computes for the segments
+    it holds are the records of the whole vector, whatever the number of ranks - so smc_host_outer_combine over the concatenated
+    records IS smc_host_reweight of the concatenated vector; the window walk (smc_samplers.jl:323-338) by records ==
+    the oracle's step-by-step walk, stopping below the ESS threshold included."""
+    rng = np.random.default_rng(3)
+    assert L.lib().smc_outer_seg() == L.OUTER_SEG == 8
+    for n in (8, 64, 200, 4096):
+        lw = rng.normal(size=n) * 6
+        lw[rng.integers(0, n, 3)] = -np.inf
+        lm, _, ess = L.host_reweight(lw)
+        whole = L.host_outer_records(lw)
+        assert L.host_outer_combine(whole, n) == (lm, ess)
+        for world in (2, 4, 8):
+            if n % (world * 8):
+                continue
+            per = n // world
+            parts = np.concatenate([L.host_outer_records(lw[r * per:(r + 1) * per]) for r in range(world)])
+            assert np.array_equal(parts, whole)
+        k = 6
+        lz = rng.normal(size=n)
+        lik = rng.normal(size=(k, n)) * 0.7 - 1.5
+        if n > 8:
+            lik[1, 2] = -np.inf; lik[2, 4] = -900.0; lik[3, 6] = 710.0
+        rec = L.host_outer_window(lw, lik)
+        e_all, j_all = L.host_outer_walk(rec, n, 0.0)
+        assert j_all == k
+        for ess_min in (0.0, float(np.sort(e_all)[2]) + 1e-9, float(e_all.max()) + 1.0):
+            e, j = L.host_outer_walk(rec, n, ess_min)
+            lw2, lz2 = L.host_outer_advance(lw, lz, lik, j)
+            olw, olz, oe, oj = ob.outer_steps(lw, lz, lik, ess_min)
+            assert j == oj and np.array_equal(bits(e), bits(oe)) and np.array_equal(bits(lw2), bits(olw)) and np.array_equal(bits(lz2), bits(olz))
+            first = int(np.argmax(e_all < ess_min)) + 1 if np.any(e_all < ess_min) else k
+            assert j == first and np.array_equal(e, e_all[:j])
+        if n % 16 == 0:      # two ranks, each walking its own half: the records side by side are the whole vector's
+            h = n // 2
+            both = np.concatenate([L.host_outer_window(lw[:h], lik[:, :h]), L.host_outer_window(lw[h:], lik[:, h:])], axis=1)
+            assert np.array_equal(both, rec)
+
+
+def test_outer_temper_resample_rw_factor_library_equals_oracle(L, ob):
+    """The tempering bisection (smc_samplers.jl:240-266), the index draw of resample!(smc) (:74-84) and the random-walk factor
+    (:87-101) of the library against the oracle's independent restatements, bit for bit; plus what they must be: the exponent
+    puts the ESS at ess_min to the bisection's resolution, the ancestors are Multinomial(n, w) (chi-square) in ascending order,
+    L L' is the reference's proposal covariance."""
+    rng = np.random.default_rng(4)
+    for n in (5, 24, 32, 512, 4096):
+        lz = rng.normal(size=n) * 3 - 100
+        for xi in (0.0, 0.3, 0.9):
+            a, b = L.host_outer_temper(lz, xi, n * 0.5), ob.outer_temper(lz, xi, n * 0.5)
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and np.array_equal(bits(a[3]), bits(b[3]))
+            if a[2]:
+                assert xi < a[0] < 1.0 and abs(a[1] - n * 0.5) < 0.02 * n and L.host_reweight(a[3])[2] == a[1]
+            else:
+                assert a[0] == 1.0 and a[1] >= n * 0.5 - 0.02 * n
+        lw = rng.normal(size=n) * 2
+        a, b = L.host_outer_resample(lw, n, 777 + n), ob.outer_resample(lw, n, 777 + n)
+        assert a.dtype == np.int32 and np.array_equal(a, b) and np.all(np.diff(a) >= 0) and 0 <= a.min() and a.max() < n
+        lw[::3] = -np.inf
+        a = L.host_outer_resample(lw, 2 * n + 1, 5)
+        assert a.size == 2 * n + 1 and np.all(np.isfinite(lw[a])) and np.array_equal(a, ob.outer_resample(lw, 2 * n + 1, 5))
+        assert np.array_equal(L.host_outer_resample(np.full(n, -np.inf), n, 1), np.arange(n))      # no weight at all: the identity
+        for d in (1, 2, 3, 4, 8):
+            if n <= d + 1:
+                continue
+            th = rng.normal(size=(n, d)) @ rng.normal(size=(d, d))
+            (La, ua), (Lb, ub) = L.host_rw_factor(th), ob.rw_factor(th)
+            assert ua == ub == (d == 1) and np.array_equal(bits(La), bits(Lb))
+            if d > 1:
+                assert np.allclose(La @ La.T, 2.83 ** 2 / d * np.cov(th.T) + 1e-10 * np.eye(d), rtol=1e-10) and np.all(np.triu(La, 1) == 0)
+            else:
+                assert La[0, 0] == pytest.approx(2.83 ** 2 * np.var(th[:, 0], ddof=1) + 1e-10, rel=1e-12)
+    n = 64
+    lw = rng.normal(size=n)
+    w = L.host_reweight(lw)[1]
+    cnt = np.zeros(n)
+    for seed in range(400):
+        cnt += np.bincount(L.host_outer_resample(lw, n, seed), minlength=n)
+    chi2 = float(np.sum((cnt - 400 * n * w) ** 2 / (400 * n * w)))
+    assert 30 < chi2 < 110, chi2                                   # 63 degrees of freedom
 
 
 _HV_SNIPPET = r"""
@@ -237,25 +338,25 @@ from sequential_monte_carlo_amd import _lib as L
 rng = np.random.default_rng(11)
 out = []
 for n in (1, 7, 64, 515, 4096):
-    om = rng.random(n); om[0] = 0.0
-    if n > 8: om[3] = 5e-320; om[5] = 2.3e-308
-    om /= om.sum()
+    lw0 = rng.normal(size=n) * 3
     lz = rng.normal(size=n)
     lik = rng.normal(size=(5, n)) * 2.0
-    if n > 8: lik[1, 2] = -np.inf; lik[2, 4] = -900.0; lik[3, 6] = 710.0
-    o, z, e, j = L.host_outer_steps(om, lz, lik, 0.0)
+    if n > 8: lik[1, 2] = -np.inf; lik[2, 4] = -900.0; lik[3, 6] = 710.0; lik[4, 1] = np.nan
+    rec = L.host_outer_window(lw0, lik)
+    e, j = L.host_outer_walk(rec, n, 0.0)
     lw = rng.normal(size=n) * 40; lw[n // 2] = -np.inf
     lm, w, es = L.host_reweight(lw)
-    out.append([o.view(np.uint64).tolist(), z.view(np.uint64).tolist(), e.view(np.uint64).tolist(), int(j),
-                float(lm).hex(), np.asarray(w).view(np.uint64).tolist(), float(es).hex()])
+    t = L.host_outer_temper(lz * 30, 0.1, n * 0.5)
+    out.append([rec.ravel().tolist(), e.view(np.uint64).tolist(), int(j), float(lm).hex(), np.asarray(w).view(np.uint64).tolist(),
+                float(es).hex(), float(t[0]).hex(), float(t[1]).hex()])
 print(json.dumps(out))
 """
 
 
 def test_host_vector_path_equals_scalar_path():
-    """The outer reweight's elementwise halves run as 4-wide vector code on hosts with AVX2 + FMA (smc_capi.hip, hv_*);
-    SMC_HOST_SCALAR=1 forces the scalar sp_log / sp_exp calls: the same bits, weights of zero, subnormal weights, -inf and
-    far-apart log-weights and lengths that are no multiple of the vector width included."""
+    """The outer level's elementwise work (exp(logw) = p 2^k, the fixed-point weights and their sums) runs as vector code on
+    hosts with AVX2 + FMA (csrc/smc_outer.hip); SMC_HOST_SCALAR=1 forces the scalar build of the same source: the same bits,
+    with -inf / NaN entries, far-apart log-weights and lengths that are no multiple of the vector width or of a segment."""
     import subprocess
     code = _HV_SNIPPET % ROOT
     runs = []
@@ -265,28 +366,6 @@ def test_host_vector_path_equals_scalar_path():
         assert r.returncode == 0, r.stderr[-2000:]
         runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert runs[0] == runs[1]
-
-
-def test_host_resample_sorted_is_numpy_choice_sorted(L):
-    """smc_host_resample_sorted == sort(Generator.choice(n, m, p=w)) for the same uniforms (numpy looks its uniforms up in
-    cumsum(p) / cumsum(p)[-1] with side="right"): the index draw of resample!(smc), smc_samplers.jl:74-84."""
-    for trial in range(60):
-        g = np.random.default_rng(trial)
-        n = int(g.integers(1, 700))
-        w = g.random(n) ** 6
-        if trial % 3 == 0:
-            w[g.integers(0, n, n // 3 + 1)] = 0.0
-        if w.sum() == 0.0:
-            w[-1] = 1.0
-        w = w / w.sum()
-        r1, r2 = np.random.default_rng(100 + trial), np.random.default_rng(100 + trial)
-        a = L.host_resample_sorted(w, np.sort(r1.random(n)))
-        assert a.dtype == np.int32 and np.array_equal(a, np.sort(r2.choice(n, size=n, replace=True, p=w)))
-        assert np.all(w[a] > 0)                                   # never an ancestor of weight zero
-    with pytest.raises(RuntimeError):
-        L.host_resample_sorted(np.array([0.5, 0.5]), np.array([0.7, 0.2]))      # not sorted
-    with pytest.raises(RuntimeError):
-        L.host_resample_sorted(np.zeros(4), np.array([0.1]))
 
 
 def test_exchange_plan_c_equals_python_and_is_consistent(L):

@@ -58,11 +58,20 @@ def test_models_and_simulate():
 LG_TMAP = smc.ThetaMap(1, [0, -1, 1, 2, -1, -1], [0.0, 1.0, 0.0, 0.0, 0.0, 1.0])    # lg_mod in device-evaluable form
 
 
-def run_dt(M=32, N=128, T=25, seed=3, comm=None, device=False):
+def _backend(lib_outer=False):
+    """the oracle's filters; lib_outer: the OUTER level by the library's host routines (LibOuter: segment records, what the
+    product runs) instead of the oracle's whole-vector twin (OracleOuter) - the two must agree bit for bit"""
+    b = OracleBackend()
+    if lib_outer:
+        b.outer = smc.smc_samplers.LibOuter()
+    return b
+
+
+def run_dt(M=32, N=128, T=25, seed=3, comm=None, device=False, lib_outer=False):
     """device=True: the sampler gets a ThetaMap, i.e. rejuvenate! takes the one-call-per-rank path (on the GPU:
     smc_pmmh_rejuvenate; here its oracle twin); False: the host loop with numpy random numbers."""
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
-    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm,
+    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=_backend(lib_outer), comm=comm,
                 theta_map=LG_TMAP if device else None)
     assert s.device_pmmh == device
     buf = io.StringIO()
@@ -172,6 +181,7 @@ def test_exchange_doubles_state_particles():
         assert grown and all(b == 2 * a for _, a, b in grown) and s.N == 64 * 2 ** len(grown)
         assert "%d particles added" % grown[0][2] in buf.getvalue()
         assert abs(s.omega.sum() - 1) < 1e-12 and np.all(np.isfinite(s.logZ))
+        assert np.array_equal(s.omega, smc._lib.host_reweight(s.logw)[1])
         x, w, _ = s._main.state()
         assert x.shape == (1, 24, s.N) and np.allclose(w.sum(axis=1), 1.0, atol=1e-12)
 
@@ -195,10 +205,10 @@ def test_smc2_online_runs_and_tracks():
     assert -1 < th[0] < 1 and th[1] > 0 and th[2] > 0
 
 
-def run_online(M=24, N=64, T=30, seed=5, comm=None, device=False, window=0, text=None):
+def run_online(M=24, N=64, T=30, seed=5, comm=None, device=False, window=0, text=None, lib_outer=False):
     """window = 0: the reference's loop, one smc²! per observation; > 0: smc2_run with that many steps per call"""
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
-    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=OracleBackend(), comm=comm,
+    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=_backend(lib_outer), comm=comm,
                 theta_map=LG_TMAP if device else None)
     smc.smc2(s, y)
     moves = 0
@@ -230,6 +240,24 @@ def test_windowed_online_run_equals_step_loop():
             assert np.array_equal(xa, xb) and np.array_equal(wa, wb) and a.psteps == b.psteps and a.t == b.t
 
 
+def test_outer_level_library_equals_oracle_twin():
+    """A9, the outer level: whole sampler runs with the library's outer routines (csrc/smc_outer.hip: segment
+    records, vector code) against the same runs with the oracle's independent whole-vector restatements (orc_outer_*): theta,
+    logZ, omega, ladders, log text - bit for bit.  (The inner filters are the oracle's in both: only the outer level differs.)"""
+    for device in (False, True):
+        a, st_a, txt_a = run_dt(device=device)
+        b, st_b, txt_b = run_dt(device=device, lib_outer=True)
+        assert txt_a == txt_b and st_a == st_b
+        assert np.array_equal(a.theta, b.theta) and np.array_equal(a.logZ, b.logZ) and np.array_equal(a.omega, b.omega)
+        for window in (0, 5):
+            ta, tb = io.StringIO(), io.StringIO()
+            a, ma, xa, wa = run_online(M=32, device=device, window=window, text=ta)
+            b, mb, xb, wb = run_online(M=32, device=device, window=window, text=tb, lib_outer=True)
+            assert ma == mb >= 1 and ta.getvalue() == tb.getvalue()
+            assert np.array_equal(a.theta, b.theta) and np.array_equal(a.logZ, b.logZ) and np.array_equal(a.logw, b.logw)
+            assert np.array_equal(a.omega, b.omega) and np.array_equal(xa, xb) and np.array_equal(wa, wb) and a.ess == b.ess
+
+
 WORKER = r'''
 import os, sys, io, json
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
@@ -240,14 +268,16 @@ from test_samplers_cpu import run_dt, run_online
 WS = int(sys.argv[5])
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=WS)
 for device in (False, True):      # host-loop rejuvenation / one-call-per-rank rejuvenation (ThetaMap)
+    # the OUTER level: the oracle's whole-vector twin with device=False, the library's segment records (what the product runs;
+    # whole-segment slices exchange records, others the likelihood increments) with device=True
     tag = sys.argv[4] + (".dev" if device else "")
-    s, stages, text = run_dt(comm=ThetaComm(dist), device=device)
+    s, stages, text = run_dt(comm=ThetaComm(dist), device=device, lib_outer=device)
     assert (s.lo, s.hi) == (dist.get_rank() * (32 // WS), (dist.get_rank() + 1) * (32 // WS))
     np.save(tag + ".%d.npy" % dist.get_rank(), np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]]))
-    # online SMC^2 with theta sharded: resample! moves whole filters between the two ranks (all-to-all)
-    so, moves, x, w = run_online(comm=ThetaComm(dist), device=device, window=5 if device else 0)
+    # online SMC^2 with theta sharded: resample! moves whole filters between the ranks (all-to-all)
+    so, moves, x, w = run_online(M=32, comm=ThetaComm(dist), device=device, window=5 if device else 0, lib_outer=device)
     assert moves >= 1
-    np.save(tag + ".online.%d.npy" % dist.get_rank(), np.concatenate([so.theta.ravel(), so.logZ, so.omega, x.ravel(), w.ravel()]))
+    np.save(tag + ".online.%d.npy" % dist.get_rank(), np.concatenate([so.theta.ravel(), so.logZ, so.omega, so.logw, x.ravel(), w.ravel()]))
 dist.destroy_process_group()
 '''
 
@@ -255,8 +285,10 @@ dist.destroy_process_group()
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_theta_sharding_world_size_2_gloo(tmp_path, world):
     """N > 1 path: `world` gloo ranks each filter their share of theta and all-gather logZ; the result is
-    identical on every rank and identical to the single-process run (stream id = global theta index).  (Two and four
-    ranks: with four, resample! of the online sampler moves filters between ranks that are not neighbours.)"""
+    identical on every rank and identical to the single-process run (stream id = global theta index; outer sums over fixed
+    segments).  With four and eight ranks resample! of the online sampler moves filters between ranks that are not neighbours;
+    with 32 parameter particles the slices of 2 and 4 ranks are whole segments of 8 (the ranks exchange segment records), those
+    of 8 ranks are not (the likelihood increments travel): the same bits every way."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = str(29500 + (os.getpid() % 2000) + world)
@@ -273,9 +305,9 @@ def test_theta_sharding_world_size_2_gloo(tmp_path, world):
             got = np.load(tag + ".%d.npy" % r)
             assert np.array_equal(got, ref), device
         # online SMC^2: the ranks' shares of the filter states, concatenated, equal the single-process run
-        so, moves, x, w = run_online(device=device)
+        so, moves, x, w = run_online(M=32, device=device)
         assert moves >= 1
-        head = np.concatenate([so.theta.ravel(), so.logZ, so.omega])
+        head = np.concatenate([so.theta.ravel(), so.logZ, so.omega, so.logw])
         parts = [np.load(tag + ".online.%d.npy" % r) for r in range(world)]
         for p_ in parts:
             assert np.array_equal(p_[:head.size], head), device
