@@ -52,6 +52,18 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 # per wave64 f64 / 64-bit-integer VALU instruction with 4 waves per SIMD, core clock 2.2-2.4 GHz under VALU load
 N_SIMD, VALU_CYCLES_PER_INST, CLOCK_GHZ = 1024, 4.4, 2.3
 
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over csrc/*.h and *.hip in name order: the same function scripts/pmc_summary.py stamps a
+    counter profile with, so that a profile taken from other kernel sources than the running build is flagged stale"""
+    import glob
+    import hashlib
+    here = os.path.join(ROOT, "sequential_monte_carlo_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(here, "*.h")) + glob.glob(os.path.join(here, "*.hip"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
 LG = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0]
 SV = [-1.0, 0.95, 0.25]
 UC = [0.2, 0.2, 3.0, 0.0, 0.0]
@@ -186,10 +198,15 @@ def main(argv=None):
     if ctx.rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
+    # the secondary sampler runs failed (an exception, or a collective that never returned): the main line is out, the exit
+    # status says so.  A stalled helper thread sits inside a collective: no orderly teardown is possible then.
+    aux_bad = getattr(ctx, "aux_failed", False)
     if getattr(ctx, "aux_stalled", False):
-        os._exit(0)          # the helper thread sits in a collective: no orderly teardown, the line is out
+        os._exit(3)
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()
+    if aux_bad:
+        sys.exit(3)
 
 
 # ---- filter workloads (c2 c3 c4 c5) ----------------------------------------------------------------------
@@ -269,8 +286,10 @@ def bench_filter(args, ctx):
             try:
                 prof = json.load(open(pmc))
                 roof["traffic"] = prof.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = "profiles/pmc_%s.json@%s (separate rocprofv3 --pmc passes, not this run)" % (
-                    args.workload, prof.get("commit", "unknown"))
+                roof["traffic_source"] = "profiles/pmc_%s.json@%s sources %s (separate rocprofv3 --pmc passes, not this run)" % (
+                    args.workload, prof.get("commit", "unknown"), prof.get("kernel_source_sha16", "unstamped"))
+                # counters of another build of the kernels say nothing about this one
+                roof["traffic_stale"] = prof.get("kernel_source_sha16") != kernel_source_hash()
                 if roof["traffic"]:
                     roof["counter_gbs"] = round(roof["traffic"] / (ms * 1e-3) / 1e9, 1)   # counter bytes / THIS run's launch time
                 wi = prof.get("valu_wave_insts_per_launch")
@@ -370,7 +389,7 @@ def run_aux(args, ctx, timeout_s=300.0):
     """The north_star scaling workloads (strong scaling, N_theta = 4096 in total) appended to a filter line.
     They run in a helper thread: if a collective of this secondary measurement ever stalled, the main line
     (already measured) must still be printed - after `timeout_s` the rank reports the timeout and the process
-    leaves through os._exit once the line is out."""
+    leaves through os._exit(3) once the line is out; an exception in a run is reported in the line and makes the exit status 3."""
     res = {}
 
     def work():
@@ -383,6 +402,7 @@ def run_aux(args, ctx, timeout_s=300.0):
                     res[algo + "_strong"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "n_gpus", "scaling", "config")}
             except Exception as e:   # noqa: BLE001
                 res[algo + "_strong"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                ctx.aux_failed = True
 
     th = threading.Thread(target=work, daemon=True)
     th.start()

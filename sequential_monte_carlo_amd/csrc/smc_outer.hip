@@ -141,6 +141,60 @@ void records_of(const double* lw, int64_t n, ORec* rec, std::vector<double>& p, 
     else records_loop_scalar(p.data(), k.data(), n, rec, qall);
 }
 
+// The pick numbers of resample!(smc): r_j, j < m, = the 64-bit halves of draw(seed, j / 2, OUTER_STREAM, 0, SLOT_OUTER) -
+// Philox4x32-10 for 8 counters at a time on hosts with AVX2 (the same integer arithmetic lane by lane: the same bits).
+void pick_numbers_scalar(uint64_t seed, int64_t m, uint64_t* r) {
+    for (int64_t j = 0; j < m; j += 2) {
+        const u32x4 w = draw(seed, (uint32_t)(j >> 1), OUTER_STREAM, 0u, SLOT_OUTER);
+        r[j] = ((uint64_t)w.v[1] << 32) | w.v[0];
+        if (j + 1 < m) r[j + 1] = ((uint64_t)w.v[3] << 32) | w.v[2];
+    }
+}
+#if defined(__x86_64__)
+}  // namespace
+#include <immintrin.h>
+namespace {
+SMC_HOSTVEC inline void mulhilo8(__m256i a, uint32_t mult, __m256i& hi, __m256i& lo) {
+    const __m256i M = _mm256_set1_epi32((int)mult);
+    const __m256i even = _mm256_mul_epu32(a, M);                          // lanes 0,2,4,6: 64-bit products
+    const __m256i odd = _mm256_mul_epu32(_mm256_srli_epi64(a, 32), M);    // lanes 1,3,5,7
+    lo = _mm256_blend_epi32(even, _mm256_slli_epi64(odd, 32), 0xAA);
+    hi = _mm256_blend_epi32(_mm256_srli_epi64(even, 32), odd, 0xAA);
+}
+SMC_HOSTVEC void pick_numbers_vec(uint64_t seed, int64_t m, uint64_t* r) {
+    const int64_t npair = (m + 1) / 2;
+    alignas(32) uint32_t o0[8], o1[8], o2[8], o3[8];
+    for (int64_t p0 = 0; p0 < npair; p0 += 8) {
+        __m256i c0 = _mm256_add_epi32(_mm256_set1_epi32((int)(uint32_t)p0), _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7));
+        __m256i c1 = _mm256_set1_epi32((int)OUTER_STREAM), c2 = _mm256_setzero_si256(), c3 = _mm256_set1_epi32((int)SLOT_OUTER);
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        for (int round = 0; round < 10; ++round) {
+            __m256i h0, l0, h1, l1;
+            mulhilo8(c0, 0xD2511F53u, h0, l0);
+            mulhilo8(c2, 0xCD9E8D57u, h1, l1);
+            const __m256i n0 = _mm256_xor_si256(_mm256_xor_si256(h1, c1), _mm256_set1_epi32((int)k0));
+            const __m256i n2 = _mm256_xor_si256(_mm256_xor_si256(h0, c3), _mm256_set1_epi32((int)k1));
+            c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        _mm256_store_si256((__m256i*)o0, c0); _mm256_store_si256((__m256i*)o1, c1);
+        _mm256_store_si256((__m256i*)o2, c2); _mm256_store_si256((__m256i*)o3, c3);
+        for (int l = 0; l < 8 && p0 + l < npair; ++l) {
+            const int64_t j = 2 * (p0 + l);
+            r[j] = ((uint64_t)o1[l] << 32) | o0[l];
+            if (j + 1 < m) r[j + 1] = ((uint64_t)o3[l] << 32) | o2[l];
+        }
+    }
+}
+#endif
+void pick_numbers(uint64_t seed, int64_t m, uint64_t* r) {
+#if defined(__x86_64__)
+    if (vec_ok()) { pick_numbers_vec(seed, m, r); return; }
+#endif
+    pick_numbers_scalar(seed, m, r);
+}
+
 struct Combined {
     double K, logmu, ess;
     uint64_t Dtot, Rtot;
@@ -325,20 +379,38 @@ extern "C" int smc_host_outer_resample(const double* logw, int64_t n, int64_t m,
         Dcum[(size_t)b] = D;
     }
     std::vector<int32_t> cnt((size_t)n, 0);
-    u32x4 rw{};
+    std::vector<uint64_t> picks((size_t)(m > 0 ? m : 1));
+    pick_numbers(seed, m, picks.data());
+    // first segment with Dcum > T: a guide table over equal slices of [0, Dtot) gives the segment the search starts at (a scan
+    // of one or two entries then: a binary search over the segment table mispredicts at every level)
+    int64_t G = 1;
+    while (G < 2 * nseg) G <<= 1;
+    int lg = 0;
+    while ((c.Dtot >> lg) >= (uint64_t)G) ++lg;
+    std::vector<int32_t> guide((size_t)G);
+    {
+        int64_t b = 0;
+        for (int64_t g = 0; g < G; ++g) {
+            const uint64_t lo = (uint64_t)g << lg;
+            while (b < nseg - 1 && Dcum[(size_t)b] <= lo) ++b;
+            guide[(size_t)g] = (int32_t)b;
+        }
+    }
+    for (int64_t b = 0; b < nseg; ++b) {                                     // fixed-point weights -> their prefix sums inside the segment
+        const int64_t i0 = b * OSEG, i1 = n < i0 + OSEG ? n : i0 + OSEG;
+        for (int64_t i = i0 + 1; i < i1; ++i) qall[(size_t)i] += qall[(size_t)i - 1];
+    }
     for (int64_t j = 0; j < m; ++j) {
-        if (!(j & 1)) rw = draw(seed, (uint32_t)(j >> 1), OUTER_STREAM, 0u, SLOT_OUTER);
-        const uint64_t r = (j & 1) ? (((uint64_t)rw.v[3] << 32) | rw.v[2]) : (((uint64_t)rw.v[1] << 32) | rw.v[0]);
         uint64_t T, lo;
-        mul64wide(r, c.Dtot, T, lo);
-        const int64_t b = std::upper_bound(Dcum.begin(), Dcum.end(), T) - Dcum.begin();   // first segment with Dcum > T (exists: T < Dtot)
+        mul64wide(picks[(size_t)j], c.Dtot, T, lo);
+        int64_t b = guide[(size_t)(T >> lg)];
+        while (Dcum[(size_t)b] <= T) ++b;                                   // ends: T < Dtot = Dcum[nseg - 1]
         const uint64_t thr = sys_threshold(T - (b ? Dcum[(size_t)b - 1] : 0), shs[(size_t)b]);
         const int64_t i0 = b * OSEG;
         const int cn = (int)(n - i0 < OSEG ? n - i0 : OSEG);
-        const uint64_t* q = qall.data() + i0;
-        uint64_t run = 0;
+        const uint64_t* C = qall.data() + i0;
         int i = 0;
-        for (; i < cn; ++i) { run += q[i]; if (run > thr) break; }
+        for (int t = 0; t < cn; ++t) i += C[t] <= thr ? 1 : 0;               // first entry whose prefix sum exceeds the threshold
         cnt[(size_t)(i0 + (i < cn ? i : cn - 1))] += 1;
     }
     int64_t o = 0;

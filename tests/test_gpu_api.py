@@ -486,6 +486,37 @@ def test_full_size_samplers_c4_c5_properties():
     be.close()
 
 
+def test_configs4_total_size_ntheta_4096_on_one_gpu():
+    """BASELINE configs[4] at its TOTAL size - density_tempered over UCSV, N_theta = 4096 x N_x = 1024, T = 200, chain 3 - on
+    one GPU (the N = 1 point of the north_star scaling curve; the 8-GPU run shards the same 4096 parameter particles):
+    deterministic replay, the bisection lands on ess_min at every resampled rung, every particle inside the prior's support,
+    executed + skipped proposals account for every chain position, posterior near the simulating parameters; and the
+    sharded outer level's view of the same vector (segment records of 8 ranks' slices) reproduces the ESS."""
+    import bench
+    from sequential_monte_carlo_amd import _lib as L
+    T, N, M, chain = 200, 1024, 4096, 3
+    y, prior, mod, tmap = bench.sampler_setup("c5dt")
+    be = smc.smc_samplers.HipBackend()
+    runs = []
+    for _ in range(2):
+        s = smc.SMC(N, M, mod, prior, chain, 0.5, seed=5, backend=be, theta_map=tmap)
+        stages = smc.density_tempered(s, y, verbose=False)
+        runs.append((s, stages))
+    (s, stages), (s2, stages2) = runs
+    assert stages == stages2 and np.array_equal(bits(s.theta), bits(s2.theta)) and np.array_equal(bits(s.logZ), bits(s2.logZ))
+    assert stages[-1][0] == 1.0 and 2 <= len(stages) <= 12
+    assert all(abs(st[1] - M * 0.5) < 2.0 and 0.0 < st[2] <= 1.0 for st in stages[:-1]) and stages[-1][1] >= M * 0.5 - 2.0
+    assert s.psteps + s.psteps_skipped == (1 + chain * (len(stages) - 1)) * M * N * T and s.psteps_skipped > 0
+    assert prior.insupport_many(s.theta).all() and np.all(np.isfinite(s.logZ))
+    th = smc.expected_parameters(s)
+    assert 0.05 < th[0] < 0.6 and 1.0 < th[1] < 5.0                                    # simulated with gamma = 0.2, x0 = 3
+    # the outer level as 8 ranks would compute it: records of the slices side by side == the whole vector's reweight
+    lw = 0.37 * s.logZ
+    rec = np.concatenate([L.host_outer_records(lw[r * 512:(r + 1) * 512]) for r in range(8)])
+    assert L.host_outer_combine(rec, M) == L.host_reweight(lw, want_w=False)[::2]
+    be.close()
+
+
 def test_filtered_summaries_on_gpu_equal_oracle_backend():
     """filtered_summaries / estimated_trend (examples/inflation_example.jl:39-55, plotting_utils.jl:116-124): the device
     quantiles are bit-identical to the oracle's, the moments agree to rounding (different summation order)."""
