@@ -77,6 +77,17 @@ int smc_step_commit(smc_handle h, int j);
  * logmu_trace / ess_trace: [T][n_theta] or NULL. */
 int smc_log_likelihood(smc_handle h, const double* y, int64_t T, double* logZ /*[n_theta]*/,
                        double* logmu_trace, double* ess_trace);
+/* Per-step filtered summaries INSIDE the multi-step calls: what README.md:33-61 and examples/inflation_example.jl:39-55 compute
+ * on the host after every bootstrap_filter! - quantile(x, weights(w), p), the weighted mean and variance - recorded at every
+ * step of the following smc_log_likelihood / smc_step_window calls of the handle, on the device, without a host round trip per
+ * observation (the README loop becomes ONE call).  component: state coordinate of the quantiles; p [np], np <= 8 (0: no
+ * quantiles); moments != 0: mean and variance of every coordinate.  np = 0 and moments = 0 switch it off again.
+ * Quantile definition: that of smc_get_quantiles (inverse of the weighted empirical CDF in the filter's integer weights).
+ * smc_get_summaries hands over the first T steps of the last such call: q [T][n_theta][np], mean / var [T][d][n_theta]
+ * (NULL: not wanted).  Single-segment filters compute them inside the LDS-resident kernel; larger ones by trailing kernels
+ * on the handle's stream after every step. */
+int smc_set_summaries(smc_handle h, int component, const double* p /*[np]*/, int np, int moments);
+int smc_get_summaries(smc_handle h, int64_t T, double* q /*[T][n_theta][np]*/, double* mean /*[T][d][n_theta]*/, double* var /*[T][d][n_theta]*/);
 /* the (x, w) the reference returns / mutates; any pointer may be NULL. w is the normalised
  * weight vector of normalize() (particles.jl:11); anc needs SMC_FLAG_ANCESTORS. */
 int smc_get_state(smc_handle h, double* x /*[d][n_theta][n_x]*/, double* w /*[n_theta][n_x]*/,

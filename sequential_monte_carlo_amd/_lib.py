@@ -27,6 +27,7 @@ EXPORTS = [
     "smc_comm_exchange_slots", "smc_host_reweight", "smc_comm_plan_exchange",
     "smc_outer_seg", "smc_host_outer_records", "smc_host_outer_combine", "smc_host_outer_window", "smc_host_outer_walk",
     "smc_host_outer_advance", "smc_host_outer_temper", "smc_host_outer_resample", "smc_host_rw_factor",
+    "smc_set_summaries", "smc_get_summaries",
 ]
 COMM_ID_BYTES = 128
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_LOGNORMAL, PRIOR_NPAR, MAX_DTHETA = 1, 2, 3, 4, 5, 8
@@ -102,6 +103,8 @@ def lib():
     L.smc_kalman_log_likelihood.argtypes = [_dp, C.c_int64, _dp, C.c_int64, C.c_int, _dp, C.c_int]
     L.smc_get_moments.argtypes = [h, _dp, _dp]
     L.smc_get_quantiles.argtypes = [h, C.c_int, _dp, C.c_int, _dp]
+    L.smc_set_summaries.argtypes = [h, C.c_int, _dp, C.c_int, C.c_int]
+    L.smc_get_summaries.argtypes = [h, C.c_int64, _dp, _dp, _dp]
     L.smc_sys_targets.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_int]
     L.smc_simulate.argtypes = [C.c_int, _dp, C.c_int64, C.c_uint64, _dp, _dp]
     L.smc_model_dim.argtypes = [C.c_int]
@@ -457,6 +460,22 @@ class Handle:
         out = np.zeros((self.n_theta, p.size))
         check(lib().smc_get_quantiles(self._h, int(component), _d(p), p.size, _d(out)))
         return out
+
+    def set_summaries(self, p=None, component=0, moments=False):
+        """per-step summaries inside the following log_likelihood / step_window calls (smc_set_summaries): weighted quantiles of
+        one state coordinate at the levels p (<= 8) and / or mean and variance of every coordinate; set_summaries() switches it off"""
+        p = np.ascontiguousarray([] if p is None else p, dtype=np.float64).ravel()
+        check(lib().smc_set_summaries(self._h, int(component), _d(p) if p.size else None, p.size, int(bool(moments))))
+        self._sum_np, self._sum_mom = int(p.size), bool(moments)
+
+    def get_summaries(self, T):
+        """(q [T][n_theta][np] or None, mean [T][d][n_theta] or None, var or None) of the first T steps of the last such call"""
+        nq, mom = getattr(self, "_sum_np", 0), getattr(self, "_sum_mom", False)
+        q = np.zeros((T, self.n_theta, nq)) if nq else None
+        mean = np.zeros((T, self.d, self.n_theta)) if mom else None
+        var = np.zeros((T, self.d, self.n_theta)) if mom else None
+        check(lib().smc_get_summaries(self._h, int(T), _d(q), _d(mean), _d(var)))
+        return q, mean, var
 
     def copy_from(self, src, mask):
         m = np.ascontiguousarray(mask, dtype=np.uint8)

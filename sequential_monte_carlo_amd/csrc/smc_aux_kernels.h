@@ -147,23 +147,6 @@ __global__ __launch_bounds__(THREADS) void k_breaks(FilterView v, uint32_t t0, u
 // digits chosen so far (LDS histograms, 64-bit integer atomics: order-free, hence bit-exact);
 // k_qselect picks the digit in which the running weight passes T.  8 passes, any Nx.
 // ---------------------------------------------------------------------------------------------
-constexpr int QMAX = 8;      // quantile levels per call
-struct QState {
-    uint64_t prefix;         // digits selected so far (high bits of the key)
-    uint64_t below;          // weight of all keys below the prefix
-    uint64_t target;         // T; ~0 marks a filter whose weights are all zero
-};
-__host__ __device__ inline uint64_t order_key(double x) {
-    const uint64_t b = d2bits(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-}
-__host__ __device__ inline double key_value(uint64_t k) { return bits2d((k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k); }
-__host__ __device__ inline uint64_t prob_to_u64(double p) {   // floor(p * 2^64) clamped
-    if (!(p > 0.0)) return 0;
-    if (p >= 1.0) return ~(uint64_t)0;
-    return (uint64_t)(p * TWO_P64);
-}
-
 // grid (nwg, ntheta)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_qhist(FilterView v, int cur, int c, int pass, int nq, const QState* st,

@@ -56,6 +56,11 @@ struct smc_filter_s {
     unsigned char* d_skip = nullptr;           // smc_set_skip: filters log_likelihood leaves out
     int32_t* d_order = nullptr;                //   and the order the one-workgroup-per-filter kernel takes them in: [ntheta] | n_active
     bool skip_on = false;
+    // per-step summaries inside the multi-step calls (smc_set_summaries / smc_get_summaries)
+    int sum_np = 0, sum_comp = 0, sum_mom = 0;
+    uint64_t sum_p64[QMAX] = {};
+    double *d_sum_q = nullptr, *d_sum_m = nullptr;   // [T][ntheta][np] | [T][2][d][ntheta]
+    int64_t sum_cap = 0, sum_T = 0;            // steps the traces hold / steps the last call recorded
     double* h_win = nullptr;                   // pinned [2][WIN_MAX][ntheta]: (logmu, ess) of the steps of a window
     int win_k = 0;                             // steps of the pending window (smc_step_window), 0 = none
     // PMMH rejuvenation state (smc_pmmh_configure / smc_pmmh_rejuvenate): this handle holds the proposal filters
@@ -400,6 +405,7 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
+    (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -542,13 +548,101 @@ extern "C" int smc_step(smc_handle h, double y_t, double* logmu, double* ess) {
 struct SeriesScope {
     FilterView& v;
     explicit SeriesScope(FilterView& view) : v(view) {}
-    ~SeriesScope() { v.want_s2 = 1; v.y = nullptr; v.trace_logmu = nullptr; v.trace_ess = nullptr; }
+    ~SeriesScope() { v.want_s2 = 1; v.y = nullptr; v.trace_logmu = nullptr; v.trace_ess = nullptr; v.sum_np = v.sum_mom = 0; v.sum_q = v.sum_m = nullptr; }
 };
+
+// ---- per-step summaries inside the multi-step calls ------------------------------------------------------------------
+static bool summaries_on(const smc_filter_s* h) { return h->sum_np > 0 || h->sum_mom != 0; }
+static int ensure_summaries(smc_handle h, int64_t T) {
+    if (T > h->sum_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m);
+        h->d_sum_q = h->d_sum_m = nullptr;
+        h->sum_cap = 0;
+        HIPCHK(dalloc(&h->d_sum_q, (size_t)T * h->v.ntheta * QMAX));
+        HIPCHK(dalloc(&h->d_sum_m, (size_t)T * 2 * h->d * h->v.ntheta));
+        h->sum_cap = T;
+    }
+    return SMC_OK;
+}
+// what the launches of a multi-step call need to know about the summaries (the scope of the call resets it)
+static void view_summaries(smc_handle h) {
+    FilterView& v = h->v;
+    v.sum_np = h->sum_np; v.sum_comp = h->sum_comp; v.sum_mom = h->sum_mom;
+    for (int j = 0; j < QMAX; ++j) v.sum_p64[j] = h->sum_p64[j];
+    v.sum_q = h->d_sum_q; v.sum_m = h->d_sum_m;
+}
+// scratch of the radix select: hist [ntheta][np][256] u64 | state [ntheta][np] | P64 [QMAX] | out [ntheta][np]
+static int ensure_qscratch(smc_handle h, int np) {
+    const size_t nst = (size_t)h->v.ntheta * np, words = nst * 256 + nst * 3 + QMAX + nst;
+    if (words > h->qcap) {
+        if (h->d_q) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_q); h->d_q = nullptr; h->qcap = 0; }
+        HIPCHK(hipMalloc((void**)&h->d_q, words * 8));
+        h->qcap = words;
+    }
+    return SMC_OK;
+}
+// The summaries of the CURRENT weights of a filter of any size into row `row` of the traces, enqueued on the handle's stream
+// behind the step that produced them (no host synchronisation): the stand-alone kernels of smc_get_quantiles /
+// smc_get_moments.  The weights must have been emitted (last_K, last_D describe them).
+static int enqueue_step_summaries(smc_handle h, int64_t row) {
+    const size_t nth = (size_t)h->v.ntheta;
+    if (h->sum_np > 0) {
+        const int np = h->sum_np;
+        const size_t nst = nth * np;
+        int rc = ensure_qscratch(h, np);
+        if (rc) return rc;
+        uint64_t* buf = h->d_q;
+        unsigned long long* hist = (unsigned long long*)buf;
+        QState* st = (QState*)(buf + nst * 256);
+        uint64_t* P64 = buf + nst * 256 + nst * 3;
+        HIPCHK(hipMemsetAsync(buf, 0, (nst * 256 + nst * 3) * 8, h->stream));
+        HIPCHK(hipMemcpyAsync(P64, h->sum_p64, sizeof h->sum_p64, hipMemcpyHostToDevice, h->stream));
+        int nwg = (int)((h->v.n + 4095) / 4096);
+        nwg = nwg > 256 ? 256 : nwg;
+        for (int pass = 0; pass < 8; ++pass) {
+            hipLaunchKernelGGL((k_qhist<256>), dim3(nwg, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, h->sum_comp, pass, np, st, hist);
+            hipLaunchKernelGGL(k_qselect, dim3(np, h->v.ntheta), dim3(256), 0, h->stream, pass, np, P64, st, hist, h->d_sum_q + (size_t)row * nst);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (h->sum_mom) {
+        const size_t nout = (size_t)h->d * nth;
+        double* base = h->d_sum_m + (size_t)row * 2 * nout;
+        hipLaunchKernelGGL((k_moments<256>), dim3(h->d, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, base, base + nout);
+        HIPCHK(hipGetLastError());
+    }
+    return SMC_OK;
+}
+
+extern "C" int smc_set_summaries(smc_handle h, int component, const double* p, int np, int moments) {
+    if (!h) return fail(SMC_EINVAL, "smc_set_summaries: NULL handle");
+    if (np < 0 || np > QMAX || (np > 0 && !p)) return fail(SMC_EINVAL, "smc_set_summaries: 0 <= np <= 8");
+    if (np > 0 && (component < 0 || component >= h->d)) return fail(SMC_EINVAL, "smc_set_summaries: component out of range");
+    h->sum_np = np; h->sum_comp = np > 0 ? component : 0; h->sum_mom = moments ? 1 : 0;
+    for (int j = 0; j < QMAX; ++j) h->sum_p64[j] = j < np ? prob_to_u64(p[j]) : 0;
+    h->sum_T = 0;
+    return SMC_OK;
+}
+
+extern "C" int smc_get_summaries(smc_handle h, int64_t T, double* q, double* mean, double* var) {
+    if (!h) return fail(SMC_EINVAL, "smc_get_summaries: NULL handle");
+    if (T < 1 || T > h->sum_T) return fail(SMC_ESTATE, "smc_get_summaries: more steps than the last multi-step call recorded");
+    if ((q && h->sum_np == 0) || ((mean || var) && !h->sum_mom)) return fail(SMC_ESTATE, "smc_get_summaries: not recorded (smc_set_summaries)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t nth = (size_t)h->v.ntheta, nout = (size_t)h->d * nth;
+    if (q) HIPCHK(hipMemcpy(q, h->d_sum_q, (size_t)T * nth * h->sum_np * 8, hipMemcpyDeviceToHost));
+    if (mean) HIPCHK(hipMemcpy2D(mean, nout * 8, h->d_sum_m, 2 * nout * 8, nout * 8, (size_t)T, hipMemcpyDeviceToHost));
+    if (var) HIPCHK(hipMemcpy2D(var, nout * 8, h->d_sum_m + nout, 2 * nout * 8, nout * 8, (size_t)T, hipMemcpyDeviceToHost));
+    return SMC_OK;
+}
 
 // The launches of log_likelihood(N, y, model) (particles.jl:132-147) for every filter of the handle, enqueued on
 // its stream: nothing here waits for the device.  y must already be in h->d_y (ensure_y + copy by the caller).
-static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_trace) {
-    const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
+static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_trace, bool summ = false) {
+    // (systematic resampling with per-step summaries: the LDS-resident summary kernels exist for the default law only)
+    const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg) && !(summ && h->v.systematic);
     SeriesScope scope(h->v);
     h->v.y = h->d_y;
     h->v.trace_logmu = want_trace ? h->d_tr_logmu : nullptr;
@@ -556,6 +650,24 @@ static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_
     h->cur = 0;
     h->v.want_s2 = want_trace ? 1 : 0;   // ess_t is read only through the traces; the last step always has it
     int rc = SMC_OK;
+    if (summ && resident) view_summaries(h);
+    if (summ && !resident) {
+        // one launch per step, every step followed by the emission of its (logmu, ess) and by the summary kernels - all on the
+        // handle's stream, nothing waits for the device
+        h->v.want_s2 = 1;
+        HIPCHK(do_init(h, y0));
+        h->t = 1; h->inited = true; h->emitted = false;
+        if ((rc = emit_if_needed(h))) return rc;
+        if ((rc = enqueue_step_summaries(h, 0))) return rc;
+        for (int64_t t = 1; t < T; ++t) {
+            HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
+            HIPCHK(do_step(h, (uint32_t)t, 0, 0.0));
+            h->cur ^= 1; h->t += 1; h->emitted = false;
+            if ((rc = emit_if_needed(h))) return rc;
+            if ((rc = enqueue_step_summaries(h, t))) return rc;
+        }
+        return SMC_OK;
+    }
     if (resident) {
         HIPCHK(do_resident(h, (int)T));
         h->cur = 0; h->t = (uint32_t)T; h->inited = true; h->emitted = true;
@@ -590,12 +702,16 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     if (want_trace && (rc = ensure_trace(h, T))) return rc;
     const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg);
     if (resident && (rc = ensure_recs(h, T))) return rc;
+    const bool summ = summaries_on(h);
+    if (summ && (rc = ensure_summaries(h, T))) return rc;
+    h->sum_T = 0;
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)T * 8, hipMemcpyHostToDevice, h->stream));
     if (h->skip_on) { h->v.skip = h->d_skip; h->v.order = h->d_order; h->v.n_active = h->d_order + h->v.ntheta; }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    rc = enqueue_log_likelihood(h, y[0], T, want_trace);
+    rc = enqueue_log_likelihood(h, y[0], T, want_trace, summ);
     h->v.skip = nullptr; h->v.order = nullptr; h->v.n_active = nullptr;
     if (rc) return rc;
+    if (summ) h->sum_T = T;
     rc = finish_timing(h, logZ);
     if (rc) return rc;
     if (logmu_trace) HIPCHK(hipMemcpy(logmu_trace, h->d_tr_logmu, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
@@ -624,11 +740,18 @@ extern "C" int smc_step_window(smc_handle h, const double* y, int k, double* log
     if ((rc = ensure_recs(h, WIN_MAX))) return rc;
     const size_t nt = (size_t)h->v.ntheta;
     if (!h->h_win) HIPCHK(hipHostMalloc((void**)&h->h_win, 2 * (size_t)WIN_MAX * nt * 8, hipHostMallocDefault));
+    const bool summ = summaries_on(h);
+    if (summ && h->v.systematic) return fail(SMC_EINVAL, "smc_step_window: per-step summaries need the default (multinomial) resampler");
+    if (summ && (rc = ensure_summaries(h, WIN_MAX))) return rc;
+    h->sum_T = 0;
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)k * 8, hipMemcpyHostToDevice, h->stream));
     h->v.y = h->d_y;
+    if (summ) view_summaries(h);
     rc = launch_window_steps(h, k);
     h->v.y = nullptr;
+    h->v.sum_np = h->v.sum_mom = 0; h->v.sum_q = h->v.sum_m = nullptr;
     if (rc) return rc;
+    if (summ) h->sum_T = k;
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -1207,13 +1330,7 @@ extern "C" int smc_get_quantiles(smc_handle h, int component, const double* p, i
     int rc = emit_if_needed(h);
     if (rc) return rc;
     const size_t nth = (size_t)h->v.ntheta, nst = nth * np;
-    // scratch: hist [ntheta][np][256] u64 | state [ntheta][np] | P64 [np] | out [ntheta][np]
-    const size_t words = nst * 256 + nst * 3 + QMAX + nst;
-    if (words > h->qcap) {   // scratch kept with the handle: the README loop asks for quantiles every step
-        if (h->d_q) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_q); h->d_q = nullptr; h->qcap = 0; }
-        HIPCHK(hipMalloc((void**)&h->d_q, words * 8));
-        h->qcap = words;
-    }
+    if ((rc = ensure_qscratch(h, np))) return rc;   // scratch kept with the handle: the README loop asks for quantiles every step
     uint64_t* buf = h->d_q;
     unsigned long long* hist = (unsigned long long*)buf;
     QState* st = (QState*)(buf + nst * 256);

@@ -93,6 +93,13 @@ struct FilterView {
     const int32_t* order;        // with skip, for the one-workgroup-per-filter kernel: a permutation of the filters, the
     const int32_t* n_active;     //    *n_active ones to run first - the workgroups that have work are then dealt evenly over
                              //    the CUs (speed only: measured 1.45x at 256 of 512 filters; scripts/skip_sweep.py)
+    // per-step filtered summaries inside the multi-step calls (smc_set_summaries; README.md:33-61 computes quantile(x, ...) after
+    // every bootstrap_filter!): weighted quantiles of state coordinate sum_comp at the levels sum_p64 (2^-64 fixed point) and
+    // mean / variance of every coordinate, written per step by the kernel that owns the filter.  sum_np = sum_mom = 0: off.
+    int sum_np, sum_comp, sum_mom;
+    uint64_t sum_p64[8];
+    double* sum_q;           // [T][ntheta][sum_np]
+    double* sum_m;           // [T][2][d][ntheta]  (mean | variance)
     int abl;                 // ablation mask: always 0 in the product (profiling builds only, -DSMC_ABLATE)
     unsigned long long* dbg; // phase stamps [workgroup][8] (profiling builds only), else nullptr
 };
@@ -109,6 +116,25 @@ struct FilterView {
 #define SMC_ABL(v, bit) 0
 #define SMC_STAMP(v, k) do { } while (0)
 #endif
+// ---- weighted quantiles: helpers shared by the stand-alone kernels (smc_aux_kernels.h) and the per-step summaries --------
+constexpr int QMAX = 8;      // quantile levels per call
+struct QState {
+    uint64_t prefix;         // digits selected so far (high bits of the key)
+    uint64_t below;          // weight of all keys below the prefix
+    uint64_t target;         // T; ~0 marks a filter whose weights are all zero
+};
+__host__ __device__ inline uint64_t order_key(double x) {
+    const uint64_t b = d2bits(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__host__ __device__ inline double key_value(uint64_t k) { return bits2d((k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k); }
+__host__ __device__ inline uint64_t prob_to_u64(double p) {   // floor(p * 2^64) clamped
+    if (!(p > 0.0)) return 0;
+    if (p >= 1.0) return ~(uint64_t)0;
+    return (uint64_t)(p * TWO_P64);
+}
+
+
 // Wave priority by phase of the step (0 = start .. 3 = normalisation): the EARLIER phase wins the issue slot.  Two
 // workgroups share a CU; the arbiter otherwise favours the older one, which then finishes ~4 us before its neighbour
 // and leaves it to run the tail of the launch alone at half occupancy.  With this rule whoever has fallen behind catches

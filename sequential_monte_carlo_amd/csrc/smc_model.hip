@@ -79,22 +79,27 @@ hipError_t launch_step<SMC_MODEL>(const FilterView& v, Geo g, int cur, uint32_t 
     SMC_GEO_SWITCH(step_t, v, cur, t, emit_prev, y, s)
 }
 
-template <int THREADS, int NP, bool SYS, bool WIN>
+template <int THREADS, int NP, bool SYS, bool WIN, bool SUMM = false>
 static hipError_t resident_sys_t(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s) {
-    const size_t lds = resident_lds_bytes<SMC_MODEL>(2 * NP * THREADS, THREADS, NP);
+    const size_t lds = resident_lds_bytes<SMC_MODEL>(2 * NP * THREADS, THREADS, NP, SUMM ? v.sum_np : -1);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool raised[16] = {};   // per instantiation and device
-    hipError_t e = raise_lds_limit(k_resident<SMC_MODEL, THREADS, NP, SYS, WIN>, lds, raised);
+    hipError_t e = raise_lds_limit(k_resident<SMC_MODEL, THREADS, NP, SYS, WIN, SUMM>, lds, raised);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_resident<SMC_MODEL, THREADS, NP, SYS, WIN>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs, t0, bin, bout, win);
+    hipLaunchKernelGGL((k_resident<SMC_MODEL, THREADS, NP, SYS, WIN, SUMM>), dim3(v.ntheta), dim3(THREADS), lds, s, v, T, recs, t0, bin, bout, win);
     return hipGetLastError();
 }
+// per-step summaries (smc_set_summaries) select the SUMM kernels; they exist for the multinomial default only (the C ABI sends
+// a systematic filter with summaries through the one-launch-per-step path)
 template <int THREADS, int NP>
 static hipError_t resident_t(const FilterView& v, int T, StepRec* recs, hipStream_t s) {
+    if (v.sum_np || v.sum_mom) return resident_sys_t<THREADS, NP, false, false, true>(v, T, recs, 0, 0, 0, nullptr, s);
     return v.systematic ? resident_sys_t<THREADS, NP, true, false>(v, T, recs, 0, 0, 0, nullptr, s)
                         : resident_sys_t<THREADS, NP, false, false>(v, T, recs, 0, 0, 0, nullptr, s);
 }
 template <int THREADS, int NP>
 static hipError_t window_t(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s) {
+    if (v.sum_np || v.sum_mom) return resident_sys_t<THREADS, NP, false, true, true>(v, T, recs, t0, bin, bout, win, s);
     return v.systematic ? resident_sys_t<THREADS, NP, true, true>(v, T, recs, t0, bin, bout, win, s)
                         : resident_sys_t<THREADS, NP, false, true>(v, T, recs, t0, bin, bout, win, s);
 }

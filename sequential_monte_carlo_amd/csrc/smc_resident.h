@@ -10,9 +10,116 @@ namespace smc {
 // per-step record written by the loop, turned into (logmu_t, ess_t) after it
 struct StepRec { double kb; uint64_t S, hi, lo; };
 
+// LDS of the per-step summaries (SUMM): weight histograms [nq][256] of the radix select, its state (prefix, below, target per
+// level) and the partial sums of the moments
+__host__ __device__ inline size_t summary_lds_words(int nq) { return (size_t)nq * 256 + 3 * QMAX + 2 * 3 * 16; }
 template <int MODEL>
-__host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int np) {
-    return (size_t)lds_padded_len(seg) * 8 * (1 + model_dim<MODEL>::value) + scr_words(threads, np) * 8;
+__host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int np, int sum_nq = -1) {
+    return (size_t)lds_padded_len(seg) * 8 * (1 + model_dim<MODEL>::value) + scr_words(threads, np) * 8 +
+           (sum_nq >= 0 ? summary_lds_words(sum_nq) * 8 : 0);
+}
+
+// Per-step filtered summaries of ONE single-segment filter whose weights (inclusive fixed-point sums Cs) and states xs sit in
+// LDS (both padded by lds_pad): what the README loop computes on the host after every bootstrap_filter! (README.md:41,51
+// quantile(x, ...); examples/inflation_example.jl:45-46 quantile(x, weights(w), p) and the weighted variance).
+//   quantiles: the definition of smc_get_quantiles (inverse of the weighted empirical CDF in the integer weights: smallest
+//              value v with sum{q_i : x_i <= v} > floor(p S)), by the same 8-pass radix select on the order-preserving key of
+//              x - histograms of 64-bit integer weights in LDS (order-free atomics), one wave per level picks the digit;
+//   moments:   sum w x and sum w x^2 with the dense weights w = q 2^-48 / (S 2^-48) of k_moments.
+// Called by every thread of the workgroup after the step's last barrier; ends with the histograms cleared for the next step.
+template <int THREADS, int NP, int D>
+__device__ __forceinline__ void resident_summaries(const FilterView& v, int th, int64_t row, const uint64_t* Cs, const double* xs, int SEGP,
+                                                   uint64_t S, uint64_t* sm) {
+    constexpr int NW = THREADS / WAVE, NQ = 2 * NP;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int nq = v.sum_np;
+    unsigned long long* hist = (unsigned long long*)sm;   // [nq][256]
+    uint64_t* st_prefix = sm + (size_t)nq * 256;          // [QMAX]
+    uint64_t* st_below = st_prefix + QMAX;                // [QMAX]
+    uint64_t* st_target = st_below + QMAX;                // [QMAX]
+    double* red = (double*)(st_target + QMAX);            // [2][3][16]
+    uint64_t q[NQ];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int i0 = 2 * (tid + k * THREADS), pp = lds_pad(i0);
+        const uint64_t c0 = Cs[pp], c1 = Cs[pp + 1], prev = i0 ? Cs[lds_pad(i0 - 1)] : 0;
+        q[2 * k] = c0 - prev;
+        q[2 * k + 1] = c1 - c0;
+    }
+    if (v.sum_mom) {
+        const double Dd = (double)S * pow2i(-48), sc = pow2i(-48);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double m = 0.0, m2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int pp = lds_pad(2 * (tid + k * THREADS));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const double x = xs[c * SEGP + pp + j];
+                    const double w = S ? ((double)q[2 * k + j] * sc) / Dd : 0.0;
+                    m += w * x;
+                    m2 += w * x * x;
+                }
+            }
+            for (int dd = WAVE / 2; dd >= 1; dd >>= 1) { m += __shfl_xor(m, dd, WAVE); m2 += __shfl_xor(m2, dd, WAVE); }
+            if (lane == 0) { red[(0 * 3 + c) * 16 + wave] = m; red[(1 * 3 + c) * 16 + wave] = m2; }
+        }
+    }
+    if (nq > 0 && S == 0) {   // collapsed filter: no quantile (workgroup-uniform)
+        if (tid < nq) v.sum_q[((size_t)row * v.ntheta + th) * nq + tid] = bits2d(0x7ff8000000000000ULL);
+    } else if (nq > 0) {
+        uint64_t key[NQ];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int pp = lds_pad(2 * (tid + k * THREADS));
+            key[2 * k] = order_key(xs[v.sum_comp * SEGP + pp]);
+            key[2 * k + 1] = order_key(xs[v.sum_comp * SEGP + pp + 1]);
+        }
+        for (int pass = 0; pass < 8; ++pass) {
+            const int hs = 64 - 8 * pass;   // the prefix is key >> hs (pass > 0)
+            for (int j = 0; j < nq; ++j) {
+                const uint64_t pref = pass ? st_prefix[j] : 0;
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+                    if (q[i] && (pass == 0 || (key[i] >> hs) == pref))
+                        atomicAdd(&hist[j * 256 + (int)((key[i] >> (hs - 8)) & 255)], (unsigned long long)q[i]);
+            }
+            __syncthreads();
+            for (int j = wave; j < nq; j += NW) {   // one wave per level: lane l owns the bins 4l .. 4l+3
+                unsigned long long* hb = hist + j * 256 + 4 * lane;
+                const uint64_t h0 = hb[0], h1 = hb[1], h2 = hb[2], h3 = hb[3];
+                hb[0] = hb[1] = hb[2] = hb[3] = 0;   // ready for the next pass / step
+                const uint64_t sum = h0 + h1 + h2 + h3;
+                const uint64_t excl = wave_incl_scan(sum, lane) - sum;
+                const uint64_t target = pass ? st_target[j] : __umul64hi(v.sum_p64[j], S);
+                const uint64_t prefix = pass ? st_prefix[j] : 0;
+                uint64_t run = (pass ? st_below[j] : 0) + excl;
+                const uint64_t hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (hh[t] && run <= target && target < run + hh[t]) {   // exactly one bin of one lane
+                        const uint64_t np_ = (prefix << 8) | (uint64_t)(4 * lane + t);
+                        st_prefix[j] = np_;
+                        st_below[j] = run;
+                        st_target[j] = target;
+                        if (pass == 7) v.sum_q[((size_t)row * v.ntheta + th) * nq + j] = key_value(np_);
+                    }
+                    run += hh[t];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (v.sum_mom) {
+        __syncthreads();
+        if (tid < D) {
+            double a = 0.0, b2 = 0.0;
+            for (int w = 0; w < NW; ++w) { a += red[(0 * 3 + tid) * 16 + w]; b2 += red[(1 * 3 + tid) * 16 + w]; }
+            v.sum_m[(((size_t)row * 2 + 0) * D + tid) * v.ntheta + th] = a;
+            v.sum_m[(((size_t)row * 2 + 1) * D + tid) * v.ntheta + th] = b2 - a * a;
+        }
+    }
 }
 
 // Window mode (WIN): the same loop over the steps [t0, t0 + T) of filters that already exist (t0 >= 1): the state is
@@ -28,7 +135,8 @@ template <int MODEL, int THREADS, int NP>
 constexpr int resident_min_waves() {
     return (THREADS == 512 && NP == 1) ? 4 : 1;
 }
-template <int MODEL, int THREADS, int NP, bool SYS = false, bool WIN = false>
+// SUMM: per-step summaries (resident_summaries) after every step, for the levels / coordinate the view names
+template <int MODEL, int THREADS, int NP, bool SYS = false, bool WIN = false, bool SUMM = false>
 __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())) void k_resident(FilterView v, int T, StepRec* recs /*[ntheta][T]*/, int t0, int bin, int bout,
                                                       double* win) {
     constexpr int D = model_dim<MODEL>::value;
@@ -39,6 +147,7 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
     double* xs = (double*)(smem + (size_t)SEGP * 8);      // [D][SEGP] padded the same way
     uint64_t* scr = (uint64_t*)(smem + (size_t)SEGP * 8 + (size_t)SEGP * 8 * D);
     uint64_t* usys = scr + scr_words(THREADS, NP) - 8;   // SYS: the steps' uniforms (tail words nobody else uses)
+    uint64_t* sm = scr + scr_words(THREADS, NP);         // SUMM: histograms and state of the per-step summaries
     constexpr int NU = (THREADS / WAVE) < 8 ? (THREADS / WAVE) : 8;
     const int tid = threadIdx.x;
     int th = blockIdx.x;
@@ -92,6 +201,9 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
         __syncthreads();
     }
 
+    if (SUMM) {   // the histograms start out empty (every selection leaves them empty again)
+        for (int i = tid; i < v.sum_np * 256; i += THREADS) sm[i] = 0;
+    }
     const bool ragged = (int)v.n != SEG;   // workgroup-uniform
     for (int t = t0; t < t0 + T; ++t) {
         const double y = v.y[t - t0];
@@ -229,6 +341,7 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
             usys[w] = ((uint64_t)uw.v[1] << 32) | uw.v[0];
         }
         __syncthreads();  // Cs, xs complete; scr free
+        if (SUMM) resident_summaries<THREADS, NP, D>(v, th, (int64_t)(t - t0), Cs, xs, SEGP, S, sm);
     }
 
     // state out: same layout as the k_step path leaves it (log_likelihood: buffer 0)

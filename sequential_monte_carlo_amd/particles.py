@@ -137,15 +137,47 @@ def bootstrap_filter_(states, weights, y, model):
     return f.out(logmu), Weights(f), f.out(ess)
 
 
+def _summaries_out(f, T):
+    """per-step summaries of the call just made, in the shapes of the README loop: quantiles [T][len(p)], mean / var [T] (scalar
+    state) or [T][d]; with a list of models a batch axis follows T"""
+    q, mean, var = f.h.get_summaries(T)
+    out = {}
+    if q is not None:
+        out["quantiles"] = q[:, 0, :] if f.single else q
+    if mean is not None:
+        mean, var = np.moveaxis(mean, 1, -1), np.moveaxis(var, 1, -1)      # [T][n_theta][d]
+        if mean.shape[-1] == 1:
+            mean, var = mean[..., 0], var[..., 0]
+        out["mean"], out["var"] = (mean[:, 0], var[:, 0]) if f.single else (mean, var)
+    return out
+
+
 def log_likelihood(N, y, model, seed=None, seg=0, device=0, streams=None, ancestors=False, trace=False,
-                   resampler="multinomial"):
+                   resampler="multinomial", quantiles=None, component=0, moments=False):
     """x, w, logZ = log_likelihood(N, y, model)   particles.jl:132-147
     trace=True additionally returns the per-step (logmu_t, ess_t).  resampler="systematic": opt-in systematic
-    resampling (same expectation, lower variance, one launch per step for big filters; not the reference's law)."""
+    resampling (same expectation, lower variance, one launch per step for big filters; not the reference's law).
+    quantiles=[...] / moments=True: the README loop (README.md:33-61: bootstrap_filter!, then quantile(x, ...) at every
+    observation) as ONE call - the per-step weighted quantiles of state coordinate `component` and / or mean and variance
+    are computed on the device inside the filter loop and returned as a dict behind the usual results."""
     if seed is None:
         seed = next(_seed_counter)
     f = _Filters(int(N), model, seed, seg, device, streams, ancestors, resampler)
     y = np.ascontiguousarray(y, dtype=np.float64)
+    summ = quantiles is not None or moments
+    if summ:
+        f.h.set_summaries(quantiles, component, moments)
+        try:
+            res = f.h.log_likelihood(y, trace=trace)
+            extra = _summaries_out(f, y.size)
+        finally:
+            f.h.set_summaries()
+        if trace:
+            logZ, lm, es = res
+            if f.single:
+                lm, es = lm[:, 0], es[:, 0]
+            return Particles(f), Weights(f), f.out(logZ), lm, es, extra
+        return Particles(f), Weights(f), f.out(res), extra
     if trace:
         logZ, lm, es = f.h.log_likelihood(y, trace=True)
         if f.single:

@@ -486,6 +486,90 @@ def test_full_size_samplers_c4_c5_properties():
     be.close()
 
 
+def test_per_step_summaries_inside_the_multi_step_calls(ob):
+    """smc_set_summaries / smc_get_summaries: the README loop (README.md:33-61: bootstrap_filter!, then quantile(x, ...) at
+    every observation; examples/inflation_example.jl:39-55) as ONE call.  The per-step weighted quantiles recorded inside
+    smc_log_likelihood and smc_step_window are, bit for bit, the oracle's sort-based quantiles after every step of its
+    step-by-step loop; mean and variance agree to rounding (different summation order).  LDS-resident kernels (single filters,
+    batches, every state coordinate, ragged particle counts), filters of several segments (trailing kernels on the stream),
+    the window API, and the results of the call itself (logZ, traces, final state) are what they are without summaries."""
+    from sequential_monte_carlo_amd import _lib as L
+    ps = [0.0, 0.05, 0.25, 0.5, 0.75, 0.999, 1.0]
+    LGR, SVR, UCR = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0], [-1.0, 0.95, 0.25], [0.2, 0.2, 3.0, 0.0, 0.0]
+    cases = ((1, LGR, 1024, 0, 3, 0, 0), (1, LGR, 1000, 0, 2, 0, 0), (3, UCR, 512, 0, 2, 2, 0), (3, UCR, 2048, 0, 1, 0, 0), (2, SVR, 4096, 0, 2, 0, 0),
+             (1, LGR, 5000, 1024, 2, 0, 0), (3, UCR, 3000, 512, 1, 1, 0), (1, LGR, 1024, 0, 2, 0, L.FLAG_SYSTEMATIC))
+    for model, raw, n, seg, nth, comp, flags in cases:
+        T = 12
+        _, y = ob.simulate(model, raw, T, 5)
+        h = L.Handle(model, nth, n, seg=seg, seed=23, flags=flags)
+        h.set_params(np.tile(raw, (nth, 1)))
+        z0, lm0, es0 = h.log_likelihood(y, trace=True)
+        x0, w0, _ = h.state(want_anc=False)
+        h.set_summaries(ps, comp, moments=True)
+        z1, lm1, es1 = h.log_likelihood(y, trace=True)
+        x1, w1, _ = h.state(want_anc=False)
+        q, mean, var = h.get_summaries(T)
+        assert np.array_equal(bits(z0), bits(z1)) and np.array_equal(bits(lm0), bits(lm1)) and np.array_equal(bits(es0), bits(es1))
+        assert np.array_equal(bits(x0), bits(x1)) and np.array_equal(bits(w0), bits(w1))
+        assert q.shape == (T, nth, len(ps)) and mean.shape == var.shape == (T, h.d, nth) and np.all(np.diff(q, axis=2) >= 0)
+        for th in range(nth):
+            f = ob.Filter(model, raw, n, seg=seg, seed=23, stream=th, systematic=bool(flags & L.FLAG_SYSTEMATIC))
+            for t in range(T):
+                if t == 0:
+                    f.bootstrap_filter(float(y[0]))
+                else:
+                    f.step(float(y[t]))
+                assert np.array_equal(bits(q[t, th]), bits(f.quantiles(ps, comp))), (model, n, seg, th, t)
+                om, ov = f.moments()
+                assert np.allclose(mean[t, :, th], om, rtol=1e-11, atol=1e-13) and np.allclose(var[t, :, th], ov, rtol=1e-8, atol=1e-12)
+        with pytest.raises(L.SmcError):
+            h.get_summaries(T + 1)
+        # quantiles only / moments only / off again
+        h.set_summaries([0.5], comp)
+        h.log_likelihood(y[:5])
+        q5, m5, v5 = h.get_summaries(5)
+        assert m5 is None and v5 is None and np.array_equal(bits(q5[:, :, 0]), bits(q[:5, :, 3]))
+        h.set_summaries(None, moments=True)
+        h.log_likelihood(y[:5])
+        q5, m5, v5 = h.get_summaries(5)
+        assert q5 is None and np.array_equal(bits(m5), bits(mean[:5])) and np.array_equal(bits(v5), bits(var[:5]))
+        h.set_summaries()
+        h.log_likelihood(y[:5])
+        with pytest.raises(L.SmcError):
+            h.get_summaries(1)
+        # the window API: k speculated steps with their summaries, then the kept prefix
+        if h.can_window and not flags:
+            h.log_likelihood(y[:4])
+            h.set_summaries(ps, comp, moments=True)
+            lmw, _ = h.step_window(y[4:10])
+            qw, mw, vw = h.get_summaries(6)
+            assert np.array_equal(bits(lmw), bits(lm0[4:10])) and np.array_equal(bits(qw), bits(q[4:10])) and np.array_equal(bits(mw), bits(mean[4:10]))
+            h.step_commit(3)
+            h.set_summaries()
+            lm_next, _ = h.step(float(y[7]))
+            assert np.array_equal(bits(lm_next), bits(lm0[7]))
+        h.close()
+    # collapsed filter: NaN quantiles at every step, the call still returns
+    h = L.Handle(2, 1, 512, seed=1)
+    h.set_params(SVR)
+    h.set_summaries([0.5])
+    h.log_likelihood(np.array([1e200, 0.1, 0.2]))
+    assert np.all(np.isnan(h.get_summaries(3)[0][0]))
+    h.close()
+    # the host mirror: the README loop as one call
+    m = smc.UnivariateLinearGaussian(**LG)
+    _, y = smc.simulate(m, 30, seed=1998)
+    x, w, logZ, s = smc.log_likelihood(1024, y, m, seed=9, quantiles=[0.25, 0.5, 0.75], moments=True)
+    xs, ws, lmu = smc.bootstrap_filter(1024, y[0], m, seed=9)
+    for t in range(30):
+        if t:
+            lmu, ws, _ = smc.bootstrap_filter_(xs, ws, y[t], m)
+        assert np.array_equal(bits(s["quantiles"][t]), bits(xs.quantile([0.25, 0.5, 0.75])))
+        mm, vv = xs.moments()
+        assert s["mean"][t] == pytest.approx(mm, rel=1e-11, abs=1e-13) and s["var"][t] == pytest.approx(vv, rel=1e-8)
+    assert s["quantiles"].shape == (30, 3) and s["mean"].shape == (30,)
+
+
 def test_configs4_total_size_ntheta_4096_on_one_gpu():
     """BASELINE configs[4] at its TOTAL size - density_tempered over UCSV, N_theta = 4096 x N_x = 1024, T = 200, chain 3 - on
     one GPU (the N = 1 point of the north_star scaling curve; the 8-GPU run shards the same 4096 parameter particles):
