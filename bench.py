@@ -494,7 +494,9 @@ def bench_sampler(args, ctx, algo, scaling, steps, warmup):
             "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s Ntheta=%d (%d/GPU) x Nx=%d T=%d chain=%d" % (names[algo], M, M // world, N, T, chain),
                        "stages_last_run": len(stages), "psteps_per_run": s.psteps,
-                       "psteps_skipped_out_of_support_per_run": s.psteps_skipped, "device_pmmh": bool(s.device_pmmh),
+                       "psteps_skipped_out_of_support_per_run": s.psteps_skipped,
+                       # device work beyond the counted steps: the dropped steps of speculated windows and the prefix a partial commit re-runs
+                       "psteps_speculated_per_run": s.psteps_speculated, "device_pmmh": bool(s.device_pmmh),
                        "posterior_mean": [float(v) for v in smc.expected_parameters(s)]},
             "ranks_seen": ctx.ranks_seen, "dist_backend": ctx.backend,
             "roofline": None, "cpu_baseline": None}
