@@ -61,6 +61,9 @@ struct smc_filter_s {
     uint64_t sum_p64[QMAX] = {};
     double *d_sum_q = nullptr, *d_sum_m = nullptr;   // [T][ntheta][np] | [T][2][d][ntheta]
     int64_t sum_cap = 0, sum_T = 0;            // steps the traces hold / steps the last call recorded
+    unsigned* d_pflags = nullptr;              // opt-in persistent step kernel (SMC_PERSIST=1): completion flags [2][ntheta * nseg]
+    int* h_perr = nullptr;                     //   and its pinned "a spin expired" word
+    int persist = -1;                          //   -1 not decided yet, 0 off / unavailable, 1 on
     double* h_win = nullptr;                   // pinned [2][WIN_MAX][ntheta]: (logmu, ess) of the steps of a window
     int win_k = 0;                             // steps of the pending window (smc_step_window), 0 = none
     // PMMH rejuvenation state (smc_pmmh_configure / smc_pmmh_rejuvenate): this handle holds the proposal filters
@@ -175,6 +178,14 @@ static hipError_t ensure_breaks(smc_filter_s* h, uint32_t t, uint32_t t_end) {
     v.brk_t0 = t;
     h->brk_count = cnt;
     return hipGetLastError();
+}
+static hipError_t do_persist(smc_filter_s* h, uint32_t t0, uint32_t t1, PersistCtl pc) {
+    switch (h->model) {
+    case MODEL_LG1D: return launch_persist<MODEL_LG1D>(h->v, h->geo, h->cur, t0, t1, pc, h->stream);
+    case MODEL_SV1D: return launch_persist<MODEL_SV1D>(h->v, h->geo, h->cur, t0, t1, pc, h->stream);
+    case MODEL_UCSV3D: return launch_persist<MODEL_UCSV3D>(h->v, h->geo, h->cur, t0, t1, pc, h->stream);
+    }
+    return hipErrorInvalidValue;
 }
 static hipError_t do_resident(smc_filter_s* h, int T) {
     switch (h->model) {
@@ -405,7 +416,8 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
-    (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m);
+    (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m); (void)hipFree(h->d_pflags);
+    if (h->h_perr) (void)hipHostFree(h->h_perr);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -675,7 +687,32 @@ static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_
         if (T == 1) h->v.want_s2 = 1;
         HIPCHK(do_init(h, y0));
         h->t = 1; h->inited = true; h->emitted = false;
-        for (int64_t t = 1; t < T; ++t) {
+        int64_t t_first = 1;
+        // OPT-IN (SMC_PERSIST=1; measured slower than one launch per step): the steps 1 .. T-2 in persistent
+        // launches, one per window of prepared break points; the last step (which carries the sum of squares) by its own launch
+        if (h->persist < 0) { const char* e = getenv("SMC_PERSIST"); h->persist = (e && atoi(e) == 1) ? 1 : 0; }
+        if (h->persist == 1 && !want_trace && h->v.nseg > 1 && !h->v.skip && !h->v.anc && T > 3) {
+            const size_t nfl = (size_t)h->v.ntheta * h->v.nseg;
+            if (!h->d_pflags) {
+                HIPCHK(dalloc(&h->d_pflags, 2 * nfl));
+                HIPCHK(hipHostMalloc((void**)&h->h_perr, 16, hipHostMallocDefault));
+            }
+            *h->h_perr = 0;
+            while (t_first < T - 1) {
+                HIPCHK(ensure_breaks(h, (uint32_t)t_first, (uint32_t)T));
+                int64_t t_end = (int64_t)h->v.brk_t0 + h->brk_count;
+                t_end = t_end > T - 1 ? T - 1 : t_end;
+                HIPCHK(hipMemsetAsync(h->d_pflags, 0, 2 * nfl * 4, h->stream));
+                PersistCtl pc{{h->d_pflags, h->d_pflags + nfl}, h->h_perr};
+                const hipError_t pe = do_persist(h, (uint32_t)t_first, (uint32_t)t_end, pc);
+                if (pe == hipErrorCooperativeLaunchTooLarge) { h->persist = 0; break; }   // not available for this filter: step by step
+                HIPCHK(pe);
+                if ((t_end - t_first) & 1) h->cur ^= 1;
+                h->t += (uint32_t)(t_end - t_first);
+                t_first = t_end;
+            }
+        }
+        for (int64_t t = t_first; t < T; ++t) {
             const int emit = h->v.want_s2 ? 1 : 2;   // 2: the records of step t-1 carry no sum of squares - (logmu, 0) from the totals alone
             if (t == T - 1) h->v.want_s2 = 1;
             HIPCHK(ensure_breaks(h, (uint32_t)t, (uint32_t)T));
@@ -714,6 +751,13 @@ extern "C" int smc_log_likelihood(smc_handle h, const double* y, int64_t T, doub
     if (summ) h->sum_T = T;
     rc = finish_timing(h, logZ);
     if (rc) return rc;
+    if (h->h_perr && *h->h_perr) {
+        *h->h_perr = 0;
+        h->persist = 0;
+        h->inited = false;
+        return fail(SMC_EHIP, "smc_log_likelihood: the persistent step kernel gave up (a workgroup waited 100 ms for the previous step: "
+                              "not every workgroup resident?); the handle falls back to one launch per step - call again");
+    }
     if (logmu_trace) HIPCHK(hipMemcpy(logmu_trace, h->d_tr_logmu, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
     if (ess_trace) HIPCHK(hipMemcpy(ess_trace, h->d_tr_ess, (size_t)T * h->v.ntheta * 8, hipMemcpyDeviceToHost));
     return SMC_OK;

@@ -49,10 +49,23 @@ __device__ __forceinline__ uint64_t lds_load_u64(lds_byte* p) { return *(lds_u64
 // the Infinity Cache anyway; written this way they leave the XCD's write-back L2 during the launch instead of at its end,
 // which shortens the gap between two dependent launches (measured on C2: 16.3 -> 15.5 us per step, same kernel span).
 typedef unsigned long long nt_v2u64 __attribute__((ext_vector_type(2)));
-template <class T>
+// WT (the persistent step kernel, k_persist): write-through (sc1) stores - what another workgroup of the SAME launch is to read
+// must leave this XCD's write-back L2 (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload, drained, then the flag)
+template <bool WT = false, class T>
 __device__ __forceinline__ void store_out(T* p, const T& val) {
     static_assert(sizeof(T) == 16, "16-byte stores");
-    __builtin_nontemporal_store(*reinterpret_cast<const nt_v2u64*>(&val), reinterpret_cast<nt_v2u64*>(p));
+    if (WT) {
+        const nt_v2u64 v2 = *reinterpret_cast<const nt_v2u64*>(&val);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v2) : "memory");
+    } else {
+        __builtin_nontemporal_store(*reinterpret_cast<const nt_v2u64*>(&val), reinterpret_cast<nt_v2u64*>(p));
+    }
+}
+template <bool WT, class T>
+__device__ __forceinline__ void store_word(T* p, T val) {   // an 8-byte record word
+    static_assert(sizeof(T) == 8, "8-byte words");
+    if (WT) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = val;
 }
 
 struct FilterView {
@@ -522,7 +535,7 @@ struct SegRec {
 
 // Cout: where the segment's inclusive sums go (global buffer or LDS), 16-B aligned.
 // PADDED: Cout is an LDS copy indexed through lds_pad().
-template <int THREADS, int NP, bool PADDED = false>
+template <int THREADS, int NP, bool PADDED = false, bool WT = false>
 __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_t* scr, uint64_t* Cout, bool want_s2) {
     constexpr int NW = THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -621,7 +634,7 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
         cc.x = excl + q[k][0];
         cc.y = cc.x + q[k][1];
         if (PADDED) *reinterpret_cast<ulonglong2*>(Cout + lds_pad(2 * (tid + k * THREADS))) = cc;
-        else store_out(reinterpret_cast<ulonglong2*>(Cout + 2 * (tid + k * THREADS)), cc);
+        else store_out<WT>(reinterpret_cast<ulonglong2*>(Cout + 2 * (tid + k * THREADS)), cc);
         basek += ktot;
     }
     if (MERGED) basek = readlane_u64(tt, NP * NW - 1);
@@ -640,17 +653,17 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
 }
 
 // normalize() of one segment into the global ping-pong buffers
-template <int THREADS, int NP>
+template <int THREADS, int NP, bool WT = false>
 __device__ __forceinline__ SegRec segment_epilogue(const FilterView& v, int nxt, int th, int sb, double (&lw)[NP][2],
                                                    uint64_t* scr) {
     uint64_t* Cout = v.C[nxt] + (size_t)th * v.npad + (size_t)sb * v.seg;
-    const SegRec rec = segment_normalize<THREADS, NP>(lw, scr, Cout, v.want_s2 != 0);
+    const SegRec rec = segment_normalize<THREADS, NP, false, WT>(lw, scr, Cout, v.want_s2 != 0);
     if (threadIdx.x == 0) {
         const size_t r = (size_t)th * v.nseg + sb;
-        v.segk[nxt][r] = rec.kb;
-        v.segS[nxt][r] = rec.S;
-        v.segS2hi[nxt][r] = rec.hi;
-        v.segS2lo[nxt][r] = rec.lo;
+        store_word<WT>(&v.segk[nxt][r], rec.kb);
+        store_word<WT>(&v.segS[nxt][r], rec.S);
+        store_word<WT>(&v.segS2hi[nxt][r], rec.hi);
+        store_word<WT>(&v.segS2lo[nxt][r], rec.lo);
     }
     return rec;
 }
@@ -777,16 +790,22 @@ __host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int n
 // ---------------------------------------------------------------------------------------------
 // SYS = opt-in systematic resampling (SMC_FLAG_SYSTEMATIC): child j takes the point T_j = floor((j Dtot + v0) / n)
 // instead of the multinomial targets between the block's break points.
-template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false>
-__global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_t t, int emit_prev, double yval) {
+// PERSIST: the body as one iteration of the persistent step kernel (k_persist below): every store another workgroup of the
+// same launch reads (x, C, the segment record) is a write-through store; the loads are plain - the caller has polled the
+// previous step's completion flags and made an agent-scope acquire before the call.
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS, bool PERSIST>
+__device__ __forceinline__ void step_body(const FilterView& v, int cur, uint32_t t, int emit_prev, double yval, char* smem) {
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
     constexpr int NQ = 2 * NP;   // particles per thread
     constexpr int NSTAGE = nstage_for(SEG);
     constexpr int SEGP = lds_padded_len(SEG);   // padded length of a staged segment in LDS
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = threadIdx.x;
-    if (v.skip && v.skip[th]) return;   // workgroup-uniform
+    int sb_ = logical_segment(blockIdx.x, v.nseg), th_ = blockIdx.y, tid_ = threadIdx.x;
+    if (PERSIST) {   // opaque per iteration: the loop around this body must not hoist everything derived from them into registers
+        asm volatile("" : "+v"(tid_));
+    }
+    const int sb = sb_, th = th_, tid = tid_;
+    if (!PERSIST && v.skip && v.skip[th]) return;   // workgroup-uniform
     const int nxt = cur ^ 1;
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
@@ -1170,7 +1189,7 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
             double2 o;
             o.x = xn[0][c];
             o.y = xn[1][c];
-            store_out(reinterpret_cast<double2*>(v.x[nxt] + ((size_t)c * v.ntheta + th) * v.npad + i0), o);
+            store_out<PERSIST>(reinterpret_cast<double2*>(v.x[nxt] + ((size_t)c * v.ntheta + th) * v.npad + i0), o);
         }
         if (v.anc) {
             int2 o;
@@ -1188,26 +1207,78 @@ __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_
         if (acc == 1.2345) v.logZ[th] = acc;
         return;
     }
-    const SegRec rec = segment_epilogue<THREADS, NP>(v, nxt, th, sb, lw, scr);
+    const SegRec rec = segment_epilogue<THREADS, NP, PERSIST>(v, nxt, th, sb, lw, scr);
     if (!MULTI && v.emit_now && tid == 0) emit_own(v, th, rec, t, false);
     SMC_STAMP(v, 7);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_finalize : (logmu, ess) of the weights currently in buffer `cur`.   grid (ntheta)
-// ---------------------------------------------------------------------------------------------
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_finalize(FilterView v, int cur, int first_emit, uint32_t t_emit) {
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false>
+__global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_t t, int emit_prev, double yval) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (v.skip && v.skip[blockIdx.x]) {   // a filter that was not run: logZ = -inf
-        if (threadIdx.x == 0) {
-            v.logZ[blockIdx.x] = -inf();
-            if (v.host_out) v.host_out[blockIdx.x] = -inf();
+    step_body<MODEL, THREADS, NP, MULTI, SYS, false>(v, cur, t, emit_prev, yval, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_persist : the steps [t0, t1) of log_likelihood's loop (particles.jl:141-144) for a multi-segment filter in ONE launch -
+// OPT-IN (SMC_PERSIST=1), measured SLOWER than one launch per step on MI355X ("persistent step kernel"):
+// kept as the measured form of that negative result.  grid (nseg, ntheta), every workgroup resident (the host checks the
+// occupancy; every spin is bounded).  Between two steps: the storing waves drain their write-through stores, a barrier, ONE
+// lane publishes the workgroup's completion flag (tag = next step); thread i of every workgroup of the filter polls the flag
+// of segment i (relaxed sc1 loads, s_sleep), one lane's agent-scope acquire, a barrier - then the step's plain loads.
+// ---------------------------------------------------------------------------------------------
+struct PersistCtl {
+    unsigned* flags[2];   // [ntheta * nseg] per buffer: t + 1 once step t of that segment is complete and visible
+    int* err;             // pinned host word: != 0 when a spin expired (not every workgroup resident)
+};
+// (second launch bound: as many waves per SIMD as two workgroups per CU need - the loop otherwise hoists its invariants into 225 registers)
+template <int MODEL, int THREADS, int NP>
+__global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : (THREADS >= 256 ? 4 : 2))) void k_persist(FilterView v_arg, int cur, uint32_t t0, uint32_t t1, PersistCtl pc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    // The view is read from the kernel-argument segment AGAIN at every step, through a pointer the compiler cannot see through:
+    // everything derived from it (Philox key schedule, base addresses, flags) is then computed inside the step, as in k_step -
+    // hoisted out of the loop it does not fit the scalar registers (110 spilled lanes, 45 spilled vector registers).
+    typedef __attribute__((address_space(4))) const uint32_t karg_word;
+    karg_word* ka = (karg_word*)__builtin_amdgcn_kernarg_segment_ptr();   // v_arg is the first argument: offset 0
+    // a word of the LDS scratch nobody else uses (the last tail word: the systematic kernels' only): "a spin of this workgroup expired"
+    int* expired_flag = (int*)((uint64_t*)(smem + (size_t)v_arg.nseg_p2 * 16) + scr_words(THREADS, NP) - 1);
+    if (tid == 0) *expired_flag = 0;
+    for (uint32_t t = t0; t < t1; ++t) {
+        asm volatile("" : "+s"(ka));
+        FilterView v;
+        {
+            static_assert(sizeof(FilterView) % 4 == 0, "whole words");
+            uint32_t words[sizeof(FilterView) / 4];
+#pragma unroll
+            for (unsigned i = 0; i < sizeof(FilterView) / 4; ++i) words[i] = ka[i];   // scalar loads from the constant address space
+            __builtin_memcpy(&v, words, sizeof(FilterView));
         }
-        return;
+        const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y;
+        if (t > t0) {
+            if (tid < v.nseg) {
+                const unsigned* f = pc.flags[cur] + (size_t)th * v.nseg + tid;
+                const unsigned long long start = __builtin_amdgcn_s_memrealtime();
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != t) {
+                    if (__builtin_amdgcn_s_memrealtime() - start > 10000000ull) { *expired_flag = 1; break; }   // 100 ms: give up
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (*expired_flag) {   // workgroup-uniform (read behind the barrier): this workgroup leaves; the others' spins expire in turn
+                if (tid == 0) *pc.err = 1;
+                return;
+            }
+        }
+        step_body<MODEL, THREADS, NP, true, false, true>(v, cur, t, 2, 0.0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(pc.flags[cur ^ 1] + (size_t)th * v.nseg + sb, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur ^= 1;
     }
-    const TableLds L = carve(smem, v.nseg_p2);
-    table_prologue<THREADS>(v, cur, blockIdx.x, L, true, first_emit != 0, t_emit);
 }
 
 }  // namespace smc

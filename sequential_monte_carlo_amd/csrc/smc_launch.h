@@ -17,6 +17,9 @@ bool geo_valid(int seg, int np, Geo& g);
 template <int MODEL> hipError_t launch_init(const FilterView& v, Geo g, int nxt, double y, hipStream_t s);
 template <int MODEL> hipError_t launch_step(const FilterView& v, Geo g, int cur, uint32_t t, int emit_prev, double y, hipStream_t s);
 template <int MODEL> hipError_t launch_resident(const FilterView& v, int T, StepRec* recs, hipStream_t s);
+// opt-in persistent step kernel: the steps [t0, t1) of a multi-segment filter in one launch; hipErrorCooperativeLaunchTooLarge when
+// the grid cannot be resident all at once (or the geometry has no instantiation): the caller then launches step by step
+template <int MODEL> hipError_t launch_persist(const FilterView& v, Geo g, int cur, uint32_t t0, uint32_t t1, PersistCtl pc, hipStream_t s);
 // window mode: steps [t0, t0 + T) from the state in buffer bin to buffer bout, (logmu, ess) of every step to win
 template <int MODEL> hipError_t launch_window(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s);
 

@@ -127,8 +127,15 @@ template <uint64_t BITS>
 __device__ __forceinline__ double fma_const(double p, double r) {
     uint32_t lo, hi;
     double d;
+    // SMC_FMAK_PINNED (the translation unit of the persistent step kernel): `volatile` keeps the constants where they are used - a
+    // loop around the step would otherwise hoist all ~60 of them into scalar registers it does not have (134 spilled lanes)
+#if defined(SMC_FMAK_PINNED)
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((uint32_t)BITS));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((uint32_t)(BITS >> 32)));
+#else
     asm("s_mov_b32 %0, %1" : "=s"(lo) : "n"((uint32_t)BITS));
     asm("s_mov_b32 %0, %1" : "=s"(hi) : "n"((uint32_t)(BITS >> 32)));
+#endif
     const double c = __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
     return d;
