@@ -1281,4 +1281,21 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : (THREADS >= 256 ? 4 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_finalize : (logmu, ess) of the weights currently in buffer `cur`.   grid (ntheta)
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_finalize(FilterView v, int cur, int first_emit, uint32_t t_emit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (v.skip && v.skip[blockIdx.x]) {   // a filter that was not run: logZ = -inf
+        if (threadIdx.x == 0) {
+            v.logZ[blockIdx.x] = -inf();
+            if (v.host_out) v.host_out[blockIdx.x] = -inf();
+        }
+        return;
+    }
+    const TableLds L = carve(smem, v.nseg_p2);
+    table_prologue<THREADS>(v, cur, blockIdx.x, L, true, first_emit != 0, t_emit);
+}
+
 }  // namespace smc
