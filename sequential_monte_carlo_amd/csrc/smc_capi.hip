@@ -361,6 +361,23 @@ extern "C" int smc_destroy(smc_handle h) {
         const size_t nwg = (size_t)h->v.ntheta * h->v.nseg;
         std::vector<unsigned long long> st(nwg * 8);
         (void)hipMemcpy(st.data(), h->v.dbg, nwg * 64, hipMemcpyDeviceToHost);
+        if (st[7] == 0x5045525349535421ull) {   // the last launch was the persistent step kernel: its own accumulators
+            double wait = 0, body = 0, pub = 0, mx_wait = 0;
+            for (size_t w = 0; w < nwg; ++w) {
+                const double steps = (double)st[w * 8];
+                wait += st[w * 8 + 1] * 0.01 / steps; body += st[w * 8 + 2] * 0.01 / steps; pub += st[w * 8 + 3] * 0.01 / steps;
+                mx_wait = std::max(mx_wait, st[w * 8 + 1] * 0.01 / steps);
+            }
+            fprintf(stderr, "[dbg] k_persist, mean over %zu workgroups, us per step: wait (poll + acquire + barrier) %.2f (max %.2f), step body %.2f, "
+                            "drain + barrier + publish %.2f\n", nwg, wait / nwg, mx_wait, body / nwg, pub / nwg);
+            (void)hipFree(h->v.dbg);
+            h->v.dbg = nullptr;
+        }
+    }
+    if (h->v.dbg) {
+        const size_t nwg = (size_t)h->v.ntheta * h->v.nseg;
+        std::vector<unsigned long long> st(nwg * 8);
+        (void)hipMemcpy(st.data(), h->v.dbg, nwg * 64, hipMemcpyDeviceToHost);
         unsigned long long t0 = ~0ull, t7 = 0;
         double ph[8] = {0};
         for (size_t w = 0; w < nwg; ++w) {

@@ -1243,6 +1243,8 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : (THREADS >= 256 ? 4 
     // a word of the LDS scratch nobody else uses (the last tail word: the systematic kernels' only): "a spin of this workgroup expired"
     int* expired_flag = (int*)((uint64_t*)(smem + (size_t)v_arg.nseg_p2 * 16) + scr_words(THREADS, NP) - 1);
     if (tid == 0) *expired_flag = 0;
+    // diagnostic builds (FilterView::dbg, allocated by the profiling build's smc_create only): where a workgroup's time goes
+    unsigned long long acc_wait = 0, acc_body = 0, acc_pub = 0, last = v_arg.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
     for (uint32_t t = t0; t < t1; ++t) {
         asm volatile("" : "+s"(ka));
         FilterView v;
@@ -1273,11 +1275,18 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : (THREADS >= 256 ? 4 
                 return;
             }
         }
+        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc_wait += now - last; last = now; }
         step_body<MODEL, THREADS, NP, true, false, true>(v, cur, t, 2, 0.0, smem);
+        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc_body += now - last; last = now; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
         __syncthreads();
         if (tid == 0) __hip_atomic_store(pc.flags[cur ^ 1] + (size_t)th * v.nseg + sb, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc_pub += now - last; last = now; }
         cur ^= 1;
+    }
+    if (v_arg.dbg && tid == 0) {   // [steps, wait (poll + acquire + barrier), step body, drain + barrier + publish] in 10 ns units; marker in word 7
+        unsigned long long* d = v_arg.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        d[0] = t1 - t0; d[1] = acc_wait; d[2] = acc_body; d[3] = acc_pub; d[7] = 0x5045525349535421ull;
     }
 }
 
