@@ -258,8 +258,8 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
 #ifdef SMC_ABLATE
     v.abl = h_abl_tmp;
     if (getenv("SMC_DBG")) {
-        if (hipMalloc((void**)&v.dbg, (size_t)v.ntheta * v.nseg * 64) != hipSuccess) v.dbg = nullptr;
-        else (void)hipMemset(v.dbg, 0, (size_t)v.ntheta * v.nseg * 64);
+        if (hipMalloc((void**)&v.dbg, (size_t)v.ntheta * v.nseg * 128) != hipSuccess) v.dbg = nullptr;   // second half: k_persist's accumulators
+        else (void)hipMemset(v.dbg, 0, (size_t)v.ntheta * v.nseg * 128);
     }
 #endif
     h->resident_ok = (v.nseg == 1) && !(flags & SMC_FLAG_NO_RESIDENT);
@@ -360,8 +360,8 @@ extern "C" int smc_destroy(smc_handle h) {
     if (h->v.dbg) {   // phase profile of the LAST k_step launch: mean over workgroups, in microseconds
         const size_t nwg = (size_t)h->v.ntheta * h->v.nseg;
         std::vector<unsigned long long> st(nwg * 8);
-        (void)hipMemcpy(st.data(), h->v.dbg, nwg * 64, hipMemcpyDeviceToHost);
-        if (st[7] == 0x5045525349535421ull) {   // the last launch was the persistent step kernel: its own accumulators
+        (void)hipMemcpy(st.data(), h->v.dbg + nwg * 8, nwg * 64, hipMemcpyDeviceToHost);
+        if (st[7] == 0x5045525349535421ull) {   // the persistent step kernel ran: its own accumulators
             double wait = 0, body = 0, pub = 0, mx_wait = 0;
             for (size_t w = 0; w < nwg; ++w) {
                 const double steps = (double)st[w * 8];
@@ -370,8 +370,6 @@ extern "C" int smc_destroy(smc_handle h) {
             }
             fprintf(stderr, "[dbg] k_persist, mean over %zu workgroups, us per step: wait (poll + acquire + barrier) %.2f (max %.2f), step body %.2f, "
                             "drain + barrier + publish %.2f\n", nwg, wait / nwg, mx_wait, body / nwg, pub / nwg);
-            (void)hipFree(h->v.dbg);
-            h->v.dbg = nullptr;
         }
     }
     if (h->v.dbg) {

@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : (THREADS >= 256 ? 4 
         cur ^= 1;
     }
     if (v_arg.dbg && tid == 0) {   // [steps, wait (poll + acquire + barrier), step body, drain + barrier + publish] in 10 ns units; marker in word 7
-        unsigned long long* d = v_arg.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        unsigned long long* d = v_arg.dbg + ((size_t)gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;   // second half of the buffer
         d[0] = t1 - t0; d[1] = acc_wait; d[2] = acc_body; d[3] = acc_pub; d[7] = 0x5045525349535421ull;
     }
 }
