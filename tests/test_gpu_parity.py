@@ -728,6 +728,46 @@ def test_launch_geometry_knobs_do_not_change_results(L, ob):
         os.environ.pop("SMC_RES_NP", None)
 
 
+def test_persistent_step_kernel_opt_in_is_bit_identical(L, ob):
+    """SMC_PERSIST=1 (opt-in; measured slower than one launch per step): the steps 1 .. T-2 of a multi-segment
+    filter run in ONE launch - write-through stores, a completion flag per workgroup and step, bounded spins.  Same step body,
+    same bits: against the oracle, and against the default path on filters the oracle would take too long for (uneven weights
+    that leave the staged window, ragged last segment, several filters per handle, every model family)."""
+    import os
+    cases = ((1, LG, 20000, 256, 2, 14), (1, LG, 300000, 1024, 1, 40), (2, SV, 70000, 512, 1, 25), (3, UC, 50000, 1024, 2, 20),
+             (1, [0.9, 1.0, 1.0, 1e-5, 0.0, 4.0], 70000, 2048, 1, 12))
+    try:
+        for model, raw, n, seg, nth, T in cases:
+            _, y = ob.simulate(model, raw if raw[3:4] != [1e-5] else [0.9, 1.0, 1.0, 0.5, 0.0, 4.0], T, 7)
+            res = []
+            for mode in ("0", "1"):
+                os.environ["SMC_PERSIST"] = mode
+                h = L.Handle(model, nth, n, seg=seg, seed=13)
+                h.set_params(np.tile(raw, (nth, 1)))
+                z = h.log_likelihood(y)
+                z2 = h.log_likelihood(y[: T - 3])          # a second, shorter series on the same handle (flags re-initialised)
+                x, w, _ = h.state(want_anc=False)
+                Craw = h.weights_raw()[0]
+                res.append((z, z2, x, w, Craw))
+                h.close()
+            for a, b in zip(res[0], res[1]):
+                assert np.array_equal(a.view(np.uint64) if a.dtype != np.uint64 else a, b.view(np.uint64) if b.dtype != np.uint64 else b), (model, n, seg)
+            if n <= 20000:
+                os.environ["SMC_PERSIST"] = "1"
+                h = L.Handle(model, nth, n, seg=seg, seed=13)
+                h.set_params(np.tile(raw, (nth, 1)))
+                z = h.log_likelihood(y)
+                x, w, _ = h.state(want_anc=False)
+                for th in range(nth):
+                    f = ob.Filter(model, raw, n, seg=seg, seed=13, stream=th)
+                    oz = f.log_likelihood(y)
+                    ox, ow, _, _ = f.state()
+                    assert bits([z[th]])[0] == bits([oz])[0] and same(x[:, th], ox) and same(w[th], ow)
+                h.close()
+    finally:
+        os.environ.pop("SMC_PERSIST", None)
+
+
 def test_sv_full_size_against_grid_filter(L):
     """C3's model at Nx = 2^20 against the deterministic grid filter (oracle/grid_filter.py; the known answer for the
     non-Gaussian model, as the Kalman likelihood is for C2): sd(logZ) at this size is ~0.01-0.02, 0.08 is > 4 sd."""
