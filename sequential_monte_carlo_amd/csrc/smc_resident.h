@@ -234,6 +234,10 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
             lds_byte* pb[NQ];
 #pragma unroll
             for (int i = 0; i < NQ; ++i) pb[i] = lds_ptr(Cs);
+            if (SMC_ABL(v, 0)) {   // ablation (profiling build): no search, a pseudo-random in-range position instead
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) pb[i] += 8 * lds_pad((int)(T2[i] >> 7) & (SEG - 1));
+            } else {
 #pragma unroll
             for (int s = SEG >> 1; s >= 1; s >>= 1) {
                 uint64_t val[NQ];
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
                 for (int i = 0; i < NQ; ++i) val[i] = lds_load_u64(pb[i] + 8 * lds_probe_off(s));
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) pb[i] += (val[i] <= T2[i]) ? 8 * lds_step_inc(s) : 0;
+            }
             }
             const int last_p = lds_pad((int)v.n - 1);
             int apos[NQ];
