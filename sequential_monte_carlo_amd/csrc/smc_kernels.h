@@ -157,6 +157,17 @@ __host__ __device__ inline uint64_t prob_to_u64(double p) {   // floor(p * 2^64)
 #endif
 #define SMC_PRIO(ph) __builtin_amdgcn_s_setprio((short)(3 - (ph)))
 
+// threadIdx.x as the helpers below read it.  SMC_TID_OPAQUE (the translation unit of the persistent step kernel): behind an empty
+// `asm volatile`, so that a loop around the step cannot hoist the lane / wave numbers and every LDS offset derived from them
+// out of it and keep them in registers the step needs (k_persist: 22 spilled registers otherwise).
+__device__ __forceinline__ int smc_tid() {
+    int t = (int)threadIdx.x;
+#if defined(SMC_TID_OPAQUE)
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / block primitives (wave64)
 // ---------------------------------------------------------------------------------------------
@@ -309,7 +320,7 @@ __device__ __forceinline__ double wave_max(double v) {
 template <int THREADS>
 __device__ __forceinline__ double block_max(double v, double* red) {
     constexpr int NW = THREADS / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int tid_ = smc_tid(), lane = tid_ & (WAVE - 1), wave = tid_ / WAVE;
     v = wave_max(v);
     if (lane == 0) red[wave] = v;
     __syncthreads();
@@ -323,7 +334,7 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 template <int THREADS>
 __device__ __forceinline__ int block_max_i32(int v, int* red) {
     constexpr int NW = THREADS / WAVE;
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int tid_ = smc_tid(), lane = tid_ & (WAVE - 1), wave = tid_ / WAVE;
     v = wave_max_i32(v);
     if (lane == 0) red[wave] = v;
     __syncthreads();
@@ -364,10 +375,11 @@ struct TablePre {
     double k1;
     uint64_t S1, hi1, lo1;
 };
-template <int THREADS>
-__device__ __forceinline__ TablePre table_preload(const FilterView& v, int cur, int th, bool emit) {
+// (VIEW: FilterView, or the same struct read in place from the kernel-argument segment - the persistent step kernel)
+template <int THREADS, class VIEW>
+__device__ __forceinline__ TablePre table_preload(const VIEW& v, int cur, int th, bool emit) {
     TablePre p{-inf(), 0, 0, 0};
-    const int tid = threadIdx.x;
+    const int tid = smc_tid();
     const size_t base = (size_t)th * v.nseg;
     if (v.nseg_p2 <= THREADS && tid < v.nseg) {
         p.k1 = v.segk[cur][base + tid];
@@ -376,11 +388,11 @@ __device__ __forceinline__ TablePre table_preload(const FilterView& v, int cur, 
     }
     return p;
 }
-template <int THREADS>
-__device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur, int th, const TableLds& L, bool emit,
+template <int THREADS, class VIEW>
+__device__ __forceinline__ uint64_t table_prologue(const VIEW& v, int cur, int th, const TableLds& L, bool emit,
                                                    bool first_emit, uint32_t t_emit, const TablePre* pre = nullptr) {
     constexpr int NW = THREADS / WAVE;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int tid = smc_tid(), lane = tid & (WAVE - 1), wave = tid / WAVE;
     const size_t base = (size_t)th * v.nseg;
     const double* sk = v.segk[cur] + base;
     const uint64_t* sS = v.segS[cur] + base;
@@ -475,12 +487,12 @@ __device__ __forceinline__ uint64_t table_prologue(const FilterView& v, int cur,
 // one record per thread (nseg_p2 <= THREADS), the exponent maximum, one wave scan of the Q_b, the wave totals, and the NE + 1
 // values picked out of the lanes that hold them.  Two barriers (the full prologue: three, plus the table traffic).  The
 // numbers are the same integers table_prologue produces.  P0 = Dcum[lo-1] (0 for lo = 0), Dc[r] = Dcum[lo+r].
-template <int THREADS, int NE>
-__device__ __forceinline__ uint64_t window_prologue(const FilterView& v, uint64_t* scr, const TablePre& pre, int lo, uint64_t& P0,
+template <int THREADS, int NE, class VIEW>
+__device__ __forceinline__ uint64_t window_prologue(const VIEW& v, uint64_t* scr, const TablePre& pre, int lo, uint64_t& P0,
                                                     uint64_t (&Dc)[NE], int (&shw)[NE], double& Kout) {
     constexpr int NW = THREADS / WAVE;
     constexpr int DEADK = (int)0x80000000;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int tid = smc_tid(), lane = tid & (WAVE - 1), wave = tid / WAVE;
     const bool live = tid < v.nseg;
     const int ki = (!live || pre.k1 == -inf()) ? DEADK : (int)pre.k1;
     const int km = block_max_i32<THREADS>(ki, (int*)scr);            // barrier 1
@@ -538,7 +550,7 @@ struct SegRec {
 template <int THREADS, int NP, bool PADDED = false, bool WT = false>
 __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_t* scr, uint64_t* Cout, bool want_s2) {
     constexpr int NW = THREADS / WAVE;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const int tid = smc_tid(), lane = tid & (WAVE - 1), wave = tid / WAVE;
     // exp(logw) = p 2^k for every particle: independent of the maximum, so it overlaps the reduction
     // a dead particle (NaN, infinite or absurd log-weight) takes p = 0 and the exponent DEAD = -2^30, below every live one
     // (lw_alive: |k| < 2^30), so that k - kb never wraps: nothing after the maximum has to ask again who is alive
@@ -653,12 +665,12 @@ __device__ __forceinline__ SegRec segment_normalize(double (&lw)[NP][2], uint64_
 }
 
 // normalize() of one segment into the global ping-pong buffers
-template <int THREADS, int NP, bool WT = false>
-__device__ __forceinline__ SegRec segment_epilogue(const FilterView& v, int nxt, int th, int sb, double (&lw)[NP][2],
+template <int THREADS, int NP, bool WT = false, class VIEW>
+__device__ __forceinline__ SegRec segment_epilogue(const VIEW& v, int nxt, int th, int sb, double (&lw)[NP][2],
                                                    uint64_t* scr) {
     uint64_t* Cout = v.C[nxt] + (size_t)th * v.npad + (size_t)sb * v.seg;
     const SegRec rec = segment_normalize<THREADS, NP, false, WT>(lw, scr, Cout, v.want_s2 != 0);
-    if (threadIdx.x == 0) {
+    if (smc_tid() == 0) {
         const size_t r = (size_t)th * v.nseg + sb;
         store_word<WT>(&v.segk[nxt][r], rec.kb);
         store_word<WT>(&v.segS[nxt][r], rec.S);
@@ -670,7 +682,8 @@ __device__ __forceinline__ SegRec segment_epilogue(const FilterView& v, int nxt,
 
 // (logmu, ess) of a single-segment filter from its own record: exactly what table_prologue's emit
 // computes for a one-entry table (K = kb).  Thread 0 only.
-__device__ __forceinline__ void emit_own(const FilterView& v, int th, const SegRec& rec, uint32_t t_emit, bool first_emit) {
+template <class VIEW>
+__device__ __forceinline__ void emit_own(const VIEW& v, int th, const SegRec& rec, uint32_t t_emit, bool first_emit) {
     const int sh = seg_shift(rec.kb, rec.kb, v.SH);
     const uint64_t D = seg_Q(rec.S, sh), R = seg_R(rec.hi, rec.lo, sh, v.SH);
     double logmu, ess;
@@ -693,7 +706,8 @@ __device__ __forceinline__ void emit_own(const FilterView& v, int th, const SegR
 // (logmu, ess = 0) of the previous step from the totals (K, Dtot) alone: what table_prologue's emit produces when the
 // records carry no sum of squares (want_s2 = 0 at that step: log_likelihood without traces, particles.jl:142 discards
 // ess).  Thread 0 of the emitting workgroup; no table, no extra barrier.
-__device__ __forceinline__ void emit_from_totals(const FilterView& v, int th, double K, uint64_t Dtot, bool first_emit, uint32_t t_emit) {
+template <class VIEW>
+__device__ __forceinline__ void emit_from_totals(const VIEW& v, int th, double K, uint64_t Dtot, bool first_emit, uint32_t t_emit) {
     double logmu, ess;
     combine_outputs(K, Dtot, 0, v.SH, v.n, logmu, ess);
     v.last_logmu[th] = logmu;
@@ -730,7 +744,7 @@ __global__ __launch_bounds__(THREADS) void k_init(FilterView v, int nxt, double 
     constexpr int D = model_dim<MODEL>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t* scr = (uint64_t*)smem;
-    const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = threadIdx.x;
+    const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y, tid = smc_tid();
     if (v.skip && v.skip[th]) return;   // workgroup-uniform
     const Params prm = v.params[th];
     const uint32_t stream = v.stream[th];
@@ -793,14 +807,14 @@ __host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int n
 // PERSIST: the body as one iteration of the persistent step kernel (k_persist below): every store another workgroup of the
 // same launch reads (x, C, the segment record) is a write-through store; the loads are plain - the caller has polled the
 // previous step's completion flags and made an agent-scope acquire before the call.
-template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS, bool PERSIST>
-__device__ __forceinline__ void step_body(const FilterView& v, int cur, uint32_t t, int emit_prev, double yval, char* smem) {
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS, bool PERSIST, class VIEW>
+__device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, int emit_prev, double yval, char* smem) {
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
     constexpr int NQ = 2 * NP;   // particles per thread
     constexpr int NSTAGE = nstage_for(SEG);
     constexpr int SEGP = lds_padded_len(SEG);   // padded length of a staged segment in LDS
-    int sb_ = logical_segment(blockIdx.x, v.nseg), th_ = blockIdx.y, tid_ = threadIdx.x;
+    int sb_ = logical_segment(blockIdx.x, v.nseg), th_ = blockIdx.y, tid_ = smc_tid();
     if (PERSIST) {   // opaque per iteration: the loop around this body must not hoist everything derived from them into registers
         asm volatile("" : "+v"(tid_));
     }
@@ -1235,26 +1249,22 @@ template <int MODEL, int THREADS, int NP>
 __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : (THREADS >= 256 ? 4 : 2))) void k_persist(FilterView v_arg, int cur, uint32_t t0, uint32_t t1, PersistCtl pc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
-    // The view is read from the kernel-argument segment AGAIN at every step, through a pointer the compiler cannot see through:
-    // everything derived from it (Philox key schedule, base addresses, flags) is then computed inside the step, as in k_step -
-    // hoisted out of the loop it does not fit the scalar registers (110 spilled lanes, 45 spilled vector registers).
-    typedef __attribute__((address_space(4))) const uint32_t karg_word;
-    karg_word* ka = (karg_word*)__builtin_amdgcn_kernarg_segment_ptr();   // v_arg is the first argument: offset 0
+    // The view is read IN PLACE from the kernel-argument segment at every step, through a pointer the compiler cannot see through:
+    // everything derived from it (Philox key schedule, base addresses, flags) is then loaded and computed where the step uses it, as
+    // in k_step - hoisted out of the loop it does not fit the scalar registers (110 spilled lanes, 45 spilled vector registers).
+    typedef __attribute__((address_space(4))) const char karg_byte;
+    karg_byte* ka = (karg_byte*)__builtin_amdgcn_kernarg_segment_ptr();   // v_arg is the first argument: offset 0
     // a word of the LDS scratch nobody else uses (the last tail word: the systematic kernels' only): "a spin of this workgroup expired"
     int* expired_flag = (int*)((uint64_t*)(smem + (size_t)v_arg.nseg_p2 * 16) + scr_words(THREADS, NP) - 1);
     if (tid == 0) *expired_flag = 0;
-    // diagnostic builds (FilterView::dbg, allocated by the profiling build's smc_create only): where a workgroup's time goes
-    unsigned long long acc_wait = 0, acc_body = 0, acc_pub = 0, last = v_arg.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    // diagnostic builds (FilterView::dbg, allocated by the profiling build's smc_create only): where a workgroup's time goes -
+    // accumulated in four more of those LDS words (wait, body, publish, last stamp), not in registers the step needs
+    unsigned long long* acc = (unsigned long long*)((uint64_t*)(smem + (size_t)v_arg.nseg_p2 * 16) + scr_words(THREADS, NP) - 5);
+    if (v_arg.dbg && tid == 0) { acc[0] = acc[1] = acc[2] = 0; acc[3] = __builtin_amdgcn_s_memrealtime(); }
     for (uint32_t t = t0; t < t1; ++t) {
         asm volatile("" : "+s"(ka));
-        FilterView v;
-        {
-            static_assert(sizeof(FilterView) % 4 == 0, "whole words");
-            uint32_t words[sizeof(FilterView) / 4];
-#pragma unroll
-            for (unsigned i = 0; i < sizeof(FilterView) / 4; ++i) words[i] = ka[i];   // scalar loads from the constant address space
-            __builtin_memcpy(&v, words, sizeof(FilterView));
-        }
+        typedef __attribute__((address_space(4))) const FilterView karg_view;
+        karg_view& v = *(karg_view*)ka;
         const int sb = logical_segment(blockIdx.x, v.nseg), th = blockIdx.y;
         if (t > t0) {
             if (tid < v.nseg) {
@@ -1275,18 +1285,18 @@ __global__ __launch_bounds__(THREADS, (THREADS >= 512 ? 4 : (THREADS >= 256 ? 4 
                 return;
             }
         }
-        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc_wait += now - last; last = now; }
+        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc[0] += now - acc[3]; acc[3] = now; }
         step_body<MODEL, THREADS, NP, true, false, true>(v, cur, t, 2, 0.0, smem);
-        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc_body += now - last; last = now; }
+        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc[1] += now - acc[3]; acc[3] = now; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
         __syncthreads();
         if (tid == 0) __hip_atomic_store(pc.flags[cur ^ 1] + (size_t)th * v.nseg + sb, t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc_pub += now - last; last = now; }
+        if (v.dbg && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); acc[2] += now - acc[3]; acc[3] = now; }
         cur ^= 1;
     }
     if (v_arg.dbg && tid == 0) {   // [steps, wait (poll + acquire + barrier), step body, drain + barrier + publish] in 10 ns units; marker in word 7
         unsigned long long* d = v_arg.dbg + ((size_t)gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;   // second half of the buffer
-        d[0] = t1 - t0; d[1] = acc_wait; d[2] = acc_body; d[3] = acc_pub; d[7] = 0x5045525349535421ull;
+        d[0] = t1 - t0; d[1] = acc[0]; d[2] = acc[1]; d[3] = acc[2]; d[7] = 0x5045525349535421ull;
     }
 }
 

@@ -2,6 +2,7 @@
 // own for all three model families: it is compiled with SMC_FMAK_PINNED (smc_spec.h), which keeps the polynomial constants of
 // exp / log / sincos next to their uses inside the step loop.  Measured slower than one launch per step.
 #define SMC_FMAK_PINNED 1
+#define SMC_TID_OPAQUE 1
 #include "smc_launch.h"
 #include <cstdlib>
 
