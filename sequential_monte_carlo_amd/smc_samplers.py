@@ -295,9 +295,7 @@ def filtered_summaries(smc, p=(0.25, 0.5, 0.75), component=0):
         raise ValueError("filtered_summaries needs the online sampler's filters (call smc2 first)")
     q = np.asarray(smc._main.quantiles(list(p), component))            # [M_local][len(p)]
     _, var = smc._main.moments()                                       # [d][M_local]
-    allq = _per_theta(smc, np.column_stack([q, np.asarray(var)[component]]))
-    w = smc.omega
-    return w @ allq[:, :-1], float(w @ allq[:, -1])
+    return _integrate(smc.omega, _per_theta(smc, np.column_stack([q, np.asarray(var)[component]])))
 
 
 def estimated_trend(smc):
@@ -495,20 +493,61 @@ def smc2_step(smc, y, t, verbose=True, out=sys.stdout):
     return smc
 
 
-def smc2_run(smc, y, t_from, t_to, window=16, verbose=True, out=sys.stdout):
+def _integrate(w, rows):
+    """[M][np + 1] per-filter (quantiles | variance) rows of every rank -> their omega-weighted means (quantiles [np], variance);
+    the products summed over the parameter particles in index order (one definition for every caller: no BLAS in between)"""
+    tot = np.add.reduce(w[:, None] * np.ascontiguousarray(rows, dtype=np.float64), axis=0)
+    return tot[:-1], float(tot[-1])
+
+
+def _window_summaries(smc, t, lik_local, j, logw_local):
+    """the integrated filtered summaries (filtered_summaries) after each of the j kept steps of a window, from the per-step
+    per-filter summaries the window launch recorded on the device: [(t + i, quantiles [np], variance)] - what the loop
+    `smc²!(smc, y, t); push!(..., get_quantiles_uc(smc))` of examples/inflation_example.jl:39-55,78-86 collects per period.
+    logw_local: this rank's outer log-weights BEFORE the window (the weights of step i follow by the window's own additions)."""
+    comp = smc._summ["component"]
+    q, _, var = smc._main.get_summaries(j)                      # [j][M_local][np], [j][d][M_local]
+    nq, per = q.shape[2], q.shape[1]
+    lw = np.array(logw_local, dtype=np.float64)
+    blocks = []
+    for i in range(j):
+        lw = lw + lik_local[i]                                   # == smc_host_outer_advance, step by step
+        blocks.append(np.concatenate([lw, q[i].ravel(), var[i][comp]]))
+    flat = np.concatenate(blocks)
+    allf = smc._gather(flat).reshape(-1, j, per * (nq + 2))      # [ranks][j][...]
+    rows = []
+    for i in range(j):
+        logw = np.concatenate([allf[r, i, :per] for r in range(allf.shape[0])])
+        qq = np.concatenate([allf[r, i, per:per * (nq + 1)].reshape(per, nq) for r in range(allf.shape[0])])
+        vv = np.concatenate([allf[r, i, per * (nq + 1):] for r in range(allf.shape[0])])
+        qi, vi = _integrate(smc.outer.reweight(logw)[1], np.column_stack([qq, vv]))
+        rows.append((t + i, qi, vi))
+    return rows
+
+
+def smc2_run(smc, y, t_from, t_to, window=16, verbose=True, out=sys.stdout, summaries=None, component=0):
     """for t in t_from:t_to  smc²!(smc, y, t)  end   (the online loop of smc_samplers.jl:308-340 / README.md:93-101),
     with the same results bit for bit, but up to `window` propagation steps per device call: between two
     resample-move decisions the inner filters only need y[t], so a window of steps runs in ONE launch with the particle
     clouds resident in LDS (smc_step_window), the host then walks through the window's outer ESS values exactly as
     smc²! would, and keeps the steps up to (and including) the first one whose ESS falls below the threshold
     (smc_step_commit; the speculated steps behind it are dropped and redone after the resample-move).
-    With sharded theta a window costs ONE all-gather of segment records (LibOuter.window_walk) instead of one exchange per step."""
+    With sharded theta a window costs ONE all-gather of segment records (LibOuter.window_walk) instead of one exchange per step.
+    summaries=[p...] (optional): additionally collect, after every step, what the example's loop collects per period
+    (examples/inflation_example.jl:78-86: get_quantiles_uc(smc) after each smc²!) - filtered_summaries(smc, p, component) -
+    from per-step summaries recorded on the device inside the window launches; returned as smc.summary_trace =
+    [(t, quantiles [len(p)], variance)], bit-identical to calling filtered_summaries after every smc2_step."""
     y = np.asarray(y, dtype=np.float64)
     t = int(t_from)
+    smc._summ = None if summaries is None else {"p": [float(v) for v in summaries], "component": int(component)}
+    smc.summary_trace = []
     while t <= t_to:
         k = min(int(window), t_to - t + 1)
         if k <= 1 or not getattr(smc._main, "can_window", False):
             smc2_step(smc, y, t, verbose, out)
+            if smc._summ:
+                qq, vv = filtered_summaries(smc, smc._summ["p"], smc._summ["component"])
+                smc.summary_trace.append((t, qq, vv))
             t += 1
             continue
         if verbose:
@@ -519,11 +558,25 @@ def smc2_run(smc, y, t_from, t_to, window=16, verbose=True, out=sys.stdout):
             _exchange(smc, y[: t - 1], verbose, out)
             if not getattr(smc._main, "can_window", False):     # exchange! may have outgrown the resident kernel
                 _step_only(smc, y, t, verbose, out)
+                if smc._summ:
+                    smc._sync_outer()
+                    qq, vv = filtered_summaries(smc, smc._summ["p"], smc._summ["component"])
+                    smc.summary_trace.append((t, qq, vv))
                 t += 1
                 continue
         _sync_params(smc)
-        lik, _ = smc._main.step_window(y[t - 1: t - 1 + k])          # [k][M_local]
-        ess, j = smc.outer.window_walk(smc, np.asarray(lik, dtype=np.float64), smc.ess_min)
+        if smc._summ:
+            smc._main.set_summaries(smc._summ["p"], smc._summ["component"], moments=True)
+        try:
+            lik, _ = smc._main.step_window(y[t - 1: t - 1 + k])          # [k][M_local]
+            lik = np.asarray(lik, dtype=np.float64)
+            logw_before = smc.logw[smc.lo:smc.hi].copy()
+            ess, j = smc.outer.window_walk(smc, lik, smc.ess_min)
+            if smc._summ:
+                smc.summary_trace.extend(_window_summaries(smc, t, lik, j, logw_before))
+        finally:
+            if smc._summ:
+                smc._main.set_summaries()                                # (the traces are read: recording off again)
         smc.ess = float(ess[-1])
         smc.t = t + j - 1
         if verbose:

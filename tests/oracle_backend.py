@@ -36,12 +36,31 @@ class OracleHandle:
         raw = [0.5, 1, 1, 1, 0, 1] if self.model_id == 1 else ([0, 0.5, 1] if self.model_id == 2 else [1, 1, 0, 0, 0])
         return ob.Filter(self.model_id, raw, self.N, seg=self.seg)
 
+    # per-step summaries inside the window (smc_set_summaries / smc_get_summaries)
+    _summ = None
+
+    def set_summaries(self, p=None, component=0, moments=False):
+        self._summ = None if (p is None and not moments) else (list(p or []), int(component), bool(moments))
+        self._summ_rows = []
+
+    def get_summaries(self, T):
+        q = np.stack([r[0] for r in self._summ_rows[:T]]) if self._summ[0] else None
+        mean = np.stack([r[1] for r in self._summ_rows[:T]]) if self._summ[2] else None
+        var = np.stack([r[2] for r in self._summ_rows[:T]]) if self._summ[2] else None
+        return q, mean, var
+
     def step_window(self, y):
         self._snap = [self._blank() for _ in self.f]
         for s, f in zip(self._snap, self.f):
             s.copy_state_from(f)
         self._win_y = np.array(y, dtype=np.float64)
-        r = [self.step(float(v)) for v in self._win_y]
+        r = []
+        self._summ_rows = []
+        for v in self._win_y:
+            r.append(self.step(float(v)))
+            if self._summ:
+                m, vv = self.moments()
+                self._summ_rows.append((self.quantiles(self._summ[0], self._summ[1]) if self._summ[0] else None, m, vv))
         return np.array([a for a, _ in r]), np.array([b for _, b in r])
 
     def step_commit(self, j):

@@ -570,6 +570,31 @@ def test_per_step_summaries_inside_the_multi_step_calls(ob):
     assert s["quantiles"].shape == (30, 3) and s["mean"].shape == (30,)
 
 
+def test_windowed_run_per_period_summaries_on_gpu():
+    """smc2_run(..., summaries=p) on the device: the per-period filtered summaries of the example's loop
+    (examples/inflation_example.jl:78-86) from the summaries the window launches record per step - quantiles bit-identical to the
+    oracle backend's (and to filtered_summaries after every smc2_step), variances to rounding; the sampler's results unchanged."""
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 24, seed=1998)
+    p = [0.1, 0.5, 0.9]
+    runs = []
+    for backend in (smc.smc_samplers.HipBackend(), OracleBackend()):
+        s = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, seed=7, backend=backend, theta_map=LG_TMAP)
+        smc.smc2(s, y)
+        smc.smc2_run(s, y, 2, 24, window=6, verbose=False, summaries=p)
+        runs.append(s)
+    h, o = runs
+    assert np.array_equal(bits(h.theta), bits(o.theta)) and np.array_equal(bits(h.logZ), bits(o.logZ)) and len(h.summary_trace) == 23
+    for (t, q, v), (t0, q0, v0) in zip(h.summary_trace, o.summary_trace):
+        assert t == t0 and np.array_equal(bits(q), bits(q0)) and v == pytest.approx(v0, rel=1e-9)
+    ref = smc.SMC(256, 24, lg_mod, lg_prior(), 2, 0.5, seed=7, backend=smc.smc_samplers.HipBackend(), theta_map=LG_TMAP)
+    smc.smc2(ref, y)
+    for t in range(2, 25):
+        smc.smc2_step(ref, y, t, verbose=False)
+        q, v = smc.filtered_summaries(ref, p)
+        assert np.array_equal(bits(q), bits(h.summary_trace[t - 2][1])) and v == pytest.approx(h.summary_trace[t - 2][2], rel=1e-9)
+    assert np.array_equal(bits(ref.theta), bits(h.theta))
+
+
 def test_configs4_total_size_ntheta_4096_on_one_gpu():
     """BASELINE configs[4] at its TOTAL size - density_tempered over UCSV, N_theta = 4096 x N_x = 1024, T = 200, chain 3 - on
     one GPU (the N = 1 point of the north_star scaling curve; the 8-GPU run shards the same 4096 parameter particles):

@@ -337,6 +337,30 @@ def test_filtered_summaries_and_trend():
     assert smc.estimated_trend(s) == pytest.approx(float(om @ (1.0 * means)), rel=1e-9)      # B = 1 in lg_mod
 
 
+def test_windowed_run_collects_per_period_summaries():
+    """smc2_run(..., summaries=p): the per-period filtered summaries the example's loop collects (examples/inflation_example.jl:
+    78-86: get_quantiles_uc(smc) after every smc²!) from summaries recorded per step inside the window launches - the same
+    numbers, bit for bit, as filtered_summaries(smc) called after every smc2_step; the sampler itself is not changed by them."""
+    _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), 30, seed=1998)
+    p = [0.25, 0.5, 0.75]
+    for device in (False, True):
+        ref = smc.SMC(64, 32, lg_mod, lg_prior(), 2, 0.5, seed=5, backend=OracleBackend(), theta_map=LG_TMAP if device else None)
+        smc.smc2(ref, y)
+        rows = []
+        for t in range(2, 31):
+            smc.smc2_step(ref, y, t, verbose=False)
+            rows.append((t,) + smc.filtered_summaries(ref, p))
+        for window in (1, 5, 16):
+            for lib_outer in (False, True):
+                s = smc.SMC(64, 32, lg_mod, lg_prior(), 2, 0.5, seed=5, backend=_backend(lib_outer), theta_map=LG_TMAP if device else None)
+                smc.smc2(s, y)
+                smc.smc2_run(s, y, 2, 30, window=window, verbose=False, summaries=p)
+                assert np.array_equal(s.theta, ref.theta) and np.array_equal(s.logZ, ref.logZ) and np.array_equal(s.logw, ref.logw)
+                assert len(s.summary_trace) == 29
+                for (t, q, v), (t0, q0, v0) in zip(s.summary_trace, rows):
+                    assert t == t0 and np.array_equal(q, q0) and v == v0, (device, window, lib_outer, t)
+
+
 def _golden_sampler_runs(backend_factory):
     """re-run the two committed sampler cases (tests/golden/sampler_vectors.json) on a backend -> dict like the fixture"""
     import json
