@@ -580,6 +580,10 @@ struct SeriesScope {
 
 // ---- per-step summaries inside the multi-step calls ------------------------------------------------------------------
 static bool summaries_on(const smc_filter_s* h) { return h->sum_np > 0 || h->sum_mom != 0; }
+// whether the LDS-resident kernels have room for the summaries' histograms next to the filter's state (160 KiB per workgroup)
+static bool summaries_fit_lds(const smc_filter_s* h) {
+    return (size_t)lds_padded_len(h->v.seg) * 8 * (size_t)(1 + h->d) + scr_words(1024, 4) * 8 + summary_lds_words(h->sum_np) * 8 <= (size_t)160 * 1024;
+}
 static int ensure_summaries(smc_handle h, int64_t T) {
     if (T > h->sum_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -669,7 +673,7 @@ extern "C" int smc_get_summaries(smc_handle h, int64_t T, double* q, double* mea
 // its stream: nothing here waits for the device.  y must already be in h->d_y (ensure_y + copy by the caller).
 static int enqueue_log_likelihood(smc_handle h, double y0, int64_t T, bool want_trace, bool summ = false) {
     // (systematic resampling with per-step summaries: the LDS-resident summary kernels exist for the default law only)
-    const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg) && !(summ && h->v.systematic);
+    const bool resident = h->resident_ok && resident_supported(h->model, h->v.seg) && !(summ && (h->v.systematic || !summaries_fit_lds(h)));
     SeriesScope scope(h->v);
     h->v.y = h->d_y;
     h->v.trace_logmu = want_trace ? h->d_tr_logmu : nullptr;
@@ -801,6 +805,7 @@ extern "C" int smc_step_window(smc_handle h, const double* y, int k, double* log
     if (!h->h_win) HIPCHK(hipHostMalloc((void**)&h->h_win, 2 * (size_t)WIN_MAX * nt * 8, hipHostMallocDefault));
     const bool summ = summaries_on(h);
     if (summ && h->v.systematic) return fail(SMC_EINVAL, "smc_step_window: per-step summaries need the default (multinomial) resampler");
+    if (summ && !summaries_fit_lds(h)) return fail(SMC_EINVAL, "smc_step_window: no LDS left for the summaries of filters this long; fewer levels, or smc_step");
     if (summ && (rc = ensure_summaries(h, WIN_MAX))) return rc;
     h->sum_T = 0;
     HIPCHK(hipMemcpyAsync(h->d_y, y, (size_t)k * 8, hipMemcpyHostToDevice, h->stream));

@@ -306,6 +306,35 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     v = mx(v, (int)dpp_u32<0x143, 0xc>(LOWEST, (uint32_t)v));
     return __builtin_amdgcn_readlane(v, WAVE - 1);
 }
+// a double moved across lanes by DPP (two 32-bit moves; lanes without a source keep `old`)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const uint64_t o = d2bits(old), b = d2bits(v);
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)o, (uint32_t)b), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(o >> 32), (uint32_t)(b >> 32));
+    return bits2d(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) { return bits2d(readlane_u64(d2bits(v), l)); }
+// sum / maximum of a double over the wave by the DPP scan ladder (fixed order: lane l accumulates the lanes below it), valid in
+// every lane; no LDS crossbar round trips (the butterfly of __shfl_xor is six dependent ds_bpermute pairs)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<0x111, 0xf>(0.0, v);
+    v += dpp_f64<0x112, 0xf>(0.0, v);
+    v += dpp_f64<0x114, 0xf>(0.0, v);
+    v += dpp_f64<0x118, 0xf>(0.0, v);
+    v += dpp_f64<0x142, 0xa>(0.0, v);
+    v += dpp_f64<0x143, 0xc>(0.0, v);
+    return readlane_f64(v, WAVE - 1);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {   // NaN-free inputs
+    auto mx = [](double a, double b) { return a > b ? a : b; };
+    v = mx(v, dpp_f64<0x111, 0xf>(-inf(), v));
+    v = mx(v, dpp_f64<0x112, 0xf>(-inf(), v));
+    v = mx(v, dpp_f64<0x114, 0xf>(-inf(), v));
+    v = mx(v, dpp_f64<0x118, 0xf>(-inf(), v));
+    v = mx(v, dpp_f64<0x142, 0xa>(-inf(), v));
+    v = mx(v, dpp_f64<0x143, 0xc>(-inf(), v));
+    return readlane_f64(v, WAVE - 1);
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int d = WAVE / 2; d >= 1; d >>= 1) {

@@ -11,8 +11,12 @@ namespace smc {
 struct StepRec { double kb; uint64_t S, hi, lo; };
 
 // LDS of the per-step summaries (SUMM): weight histograms [nq][256] of the radix select, its state (prefix, below, target per
-// level) and the partial sums of the moments
-__host__ __device__ inline size_t summary_lds_words(int nq) { return (size_t)nq * 256 + 3 * QMAX + 2 * 3 * 16; }
+// level), the partial sums of the moments; and of the usual (value-binned) selection: one histogram of SUMM_BINS bins shared by
+// the levels, SUMM_CAND candidates (key, weight) per level, the chosen bin and the candidate count per level, the waves' key range
+constexpr int SUMM_BINS = 1024, SUMM_CAND = 64;
+__host__ __device__ inline size_t summary_lds_words(int nq) {
+    return (size_t)nq * 256 + 3 * QMAX + 2 * 3 * 16 + SUMM_BINS + (size_t)nq * SUMM_CAND * 2 + 2 * QMAX + 2 * 16;
+}
 template <int MODEL>
 __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int np, int sum_nq = -1) {
     return (size_t)lds_padded_len(seg) * 8 * (1 + model_dim<MODEL>::value) + scr_words(threads, np) * 8 +
@@ -23,8 +27,14 @@ __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int n
 // LDS (both padded by lds_pad): what the README loop computes on the host after every bootstrap_filter! (README.md:41,51
 // quantile(x, ...); examples/inflation_example.jl:45-46 quantile(x, weights(w), p) and the weighted variance).
 //   quantiles: the definition of smc_get_quantiles (inverse of the weighted empirical CDF in the integer weights: smallest
-//              value v with sum{q_i : x_i <= v} > floor(p S)), by the same 8-pass radix select on the order-preserving key of
-//              x - histograms of 64-bit integer weights in LDS (order-free atomics), one wave per level picks the digit;
+//              value v with sum{q_i : x_i <= v} > floor(p S)).  Any selection that narrows by a MONOTONE map of x finds that same
+//              particle, so the usual path bins by value instead of by key digits (the top key bytes - sign and exponent - of a
+//              filter's cloud are all alike: a thousand LDS atomics on two or three addresses per pass): the range of the keys
+//              that carry weight (one wave reduction), ONE histogram of 1024 equal-width value bins of the 64-bit integer weights
+//              for all levels (order-free LDS atomics, about one particle per bin), one wave per level picks its bin, the few
+//              particles of that bin are collected and ranked inside the wave - four barriers.  Whenever that does not apply
+//              (a non-finite value carrying weight, an empty or overflowing range, more than 64 particles in a chosen bin) the
+//              step falls back to the 8-pass radix select on the order-preserving key, one wave per level picking the digit;
 //   moments:   sum w x and sum w x^2 with the dense weights w = q 2^-48 / (S 2^-48) of k_moments.
 // Called by every thread of the workgroup after the step's last barrier; ends with the histograms cleared for the next step.
 template <int THREADS, int NP, int D>
@@ -62,7 +72,8 @@ __device__ __forceinline__ void resident_summaries(const FilterView& v, int th, 
                     m2 += w * x * x;
                 }
             }
-            for (int dd = WAVE / 2; dd >= 1; dd >>= 1) { m += __shfl_xor(m, dd, WAVE); m2 += __shfl_xor(m2, dd, WAVE); }
+            m = wave_sum_f64(m);
+            m2 = wave_sum_f64(m2);
             if (lane == 0) { red[(0 * 3 + c) * 16 + wave] = m; red[(1 * 3 + c) * 16 + wave] = m2; }
         }
     }
@@ -70,12 +81,108 @@ __device__ __forceinline__ void resident_summaries(const FilterView& v, int th, 
         if (tid < nq) v.sum_q[((size_t)row * v.ntheta + th) * nq + tid] = bits2d(0x7ff8000000000000ULL);
     } else if (nq > 0) {
         uint64_t key[NQ];
+        double xv[NQ];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int pp = lds_pad(2 * (tid + k * THREADS));
-            key[2 * k] = order_key(xs[v.sum_comp * SEGP + pp]);
-            key[2 * k + 1] = order_key(xs[v.sum_comp * SEGP + pp + 1]);
+            xv[2 * k] = xs[v.sum_comp * SEGP + pp];
+            xv[2 * k + 1] = xs[v.sum_comp * SEGP + pp + 1];
+            key[2 * k] = order_key(xv[2 * k]);
+            key[2 * k + 1] = order_key(xv[2 * k + 1]);
         }
+        // ---- the usual path: selection through equal-width value bins ----
+        unsigned long long* hbin = (unsigned long long*)(red + 2 * 3 * 16);   // [SUMM_BINS]
+        uint64_t* cand = (uint64_t*)(hbin + SUMM_BINS);                        // [nq][SUMM_CAND][2]
+        uint64_t* st_bin = cand + (size_t)nq * SUMM_CAND * 2;                  // [QMAX]
+        unsigned* cnt = (unsigned*)(st_bin + QMAX);                            // [QMAX] (two per word)
+        uint64_t* kmm = st_bin + 2 * QMAX;                                     // [2][16]
+        double vhi = -inf(), vlo = -inf();   // the largest value and the largest negated value that carry weight
+        bool odd = false;                     // ... or a non-finite one
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            if (q[i]) {
+                odd = odd || !(fabs(xv[i]) < inf());
+                vhi = xv[i] > vhi ? xv[i] : vhi;
+                vlo = -xv[i] > vlo ? -xv[i] : vlo;
+            }
+        odd = __ballot(odd) != 0;
+        vhi = wave_max_f64(odd ? 0.0 : vhi);
+        vlo = wave_max_f64(odd ? 0.0 : vlo);
+        if (lane == 0) { kmm[wave] = d2bits(odd ? inf() : vhi); kmm[16 + wave] = d2bits(vlo); }
+        if (tid < nq) cnt[tid] = 0;
+        __syncthreads();
+        vhi = vlo = -inf();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { const double a = bits2d(kmm[w]), b = bits2d(kmm[16 + w]); vhi = a > vhi ? a : vhi; vlo = b > vlo ? b : vlo; }
+        // (any positive factor gives a monotone map: the hardware's approximate reciprocal will do)
+        const double lo = -vlo, hi = vhi, scale = (double)SUMM_BINS * __builtin_amdgcn_rcp(hi - lo);
+        // workgroup-uniform: every value that carries weight is finite, they are not all alike, the bin width is a normal number
+        bool binned = fabs(lo) < inf() && fabs(hi) < inf() && lo < hi && scale < inf();
+        if (binned) {
+            constexpr int PER = SUMM_BINS / WAVE;
+            static_assert(PER == 16, "one row of lanes picks the bin");
+            int bin[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int b = (int)((xv[i] - lo) * scale);   // monotone in x: differences, products and truncation all are
+                bin[i] = b < SUMM_BINS - 1 ? b : SUMM_BINS - 1;
+                // bin b lives at word (b mod 16) * 64 + b / 16: the lanes of the wave that sums 16 consecutive bins each read
+                // consecutive words (16 l + t at t * 64 + l) instead of all hitting the same two banks
+                if (q[i]) atomicAdd(&hbin[(bin[i] & (PER - 1)) * WAVE + (bin[i] >> 4)], (unsigned long long)q[i]);
+            }
+            __syncthreads();
+            for (int j = wave; j < nq; j += NW) {   // one wave per level: lane l sums the bins 16 l .. 16 l + 15
+                uint64_t sum = 0;
+#pragma unroll 4
+                for (int t = 0; t < PER; ++t) sum += hbin[t * WAVE + lane];
+                const uint64_t excl = wave_incl_scan(sum, lane) - sum;
+                const uint64_t target = __umul64hi(v.sum_p64[j], S);
+                const unsigned long long own = __ballot(sum && excl <= target && target < excl + sum);   // exactly one lane
+                const int L = own ? __builtin_ctzll(own) : 0;
+                // ... and the 16 bins of that lane, one per lane of the first row
+                const uint64_t h = lane < PER ? hbin[lane * WAVE + L] : 0;
+                uint64_t incl = h;
+                incl = dpp_add_u64<0x111>(incl);
+                incl = dpp_add_u64<0x112>(incl);
+                incl = dpp_add_u64<0x114>(incl);
+                incl = dpp_add_u64<0x118>(incl);
+                const uint64_t run = readlane_u64(excl, L) + incl - h;
+                if (lane < PER && h && run <= target && target < run + h) { st_bin[j] = (uint64_t)(PER * L + lane); st_below[j] = run; st_target[j] = target; }
+            }
+            __syncthreads();
+            for (int j = 0; j < nq; ++j) {   // the particles of the chosen bins, in any order
+                const int sb = (int)st_bin[j];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+                    if (q[i] && bin[i] == sb) {
+                        const unsigned idx = atomicAdd(&cnt[j], 1u);
+                        if (idx < (unsigned)SUMM_CAND) { cand[((size_t)j * SUMM_CAND + idx) * 2] = key[i]; cand[((size_t)j * SUMM_CAND + idx) * 2 + 1] = q[i]; }
+                    }
+            }
+            for (int i = tid; i < SUMM_BINS; i += THREADS) hbin[i] = 0;   // ready for the next step
+            __syncthreads();
+            for (int j = 0; j < nq; ++j) binned = binned && cnt[j] <= (unsigned)SUMM_CAND;   // workgroup-uniform
+            if (binned) {
+                for (int j = wave; j < nq; j += NW) {   // one wave per level ranks its candidates: lane l holds candidate l
+                    const int c = __builtin_amdgcn_readfirstlane((int)cnt[j]);
+                    const uint64_t ck = lane < c ? cand[((size_t)j * SUMM_CAND + lane) * 2] : ~0ULL;
+                    const uint64_t cw = lane < c ? cand[((size_t)j * SUMM_CAND + lane) * 2 + 1] : 0;
+                    uint64_t less = st_below[j], upto = less;   // weight of everything below / not above this candidate
+                    for (int m = 0; m < c; ++m) {
+                        const uint64_t km = readlane_u64(ck, m), wm = readlane_u64(cw, m);
+                        less += km < ck ? wm : 0;
+                        upto += km <= ck ? wm : 0;
+                    }
+                    // the candidates whose value the target falls on (all of them hold the same key): the quantile
+                    const uint64_t tg = st_target[j];
+                    const unsigned long long hit = __ballot(lane < c && less <= tg && tg < upto);
+                    const uint64_t best = readlane_u64(ck, hit ? __builtin_ctzll(hit) : 0);
+                    if (lane == 0) v.sum_q[((size_t)row * v.ntheta + th) * nq + j] = key_value(best);
+                }
+            }
+        }
+        // ---- otherwise: radix select on the key, eight digits of eight bits ----
+        if (!binned)
         for (int pass = 0; pass < 8; ++pass) {
             const int hs = 64 - 8 * pass;   // the prefix is key >> hs (pass > 0)
             for (int j = 0; j < nq; ++j) {
@@ -202,7 +309,7 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
     }
 
     if (SUMM) {   // the histograms start out empty (every selection leaves them empty again)
-        for (int i = tid; i < v.sum_np * 256; i += THREADS) sm[i] = 0;
+        for (int i = tid; i < (int)summary_lds_words(v.sum_np); i += THREADS) sm[i] = 0;
     }
     const bool ragged = (int)v.n != SEG;   // workgroup-uniform
     for (int t = t0; t < t0 + T; ++t) {
