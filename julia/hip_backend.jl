@@ -286,15 +286,19 @@ hip_prior(::Any) = nothing
 prior_components(p::Distributions.Product) = p.v
 prior_components(p::UnivariateDistribution) = [p]
 prior_components(::Any) = nothing
+if isdefined(Distributions, :ProductDistribution)      # what product_distribution returns in newer Distributions.jl
+    @eval prior_components(p::Distributions.ProductDistribution) = collect(p.dists)
+end
 
 # smc.model(θ) as data: raw[k] = θ[raw_from[k]] or a constant.  Found by probing the closure: the parameter row at θ0 and at θ0
 # with one component changed - an entry that moves must BE that component (README.md:75-79, examples:227-230 are of this kind)
-function infer_theta_map(model, θ0::Vector{Float64})
-    raw0 = hip_model(model(θ0))[2]
+function infer_theta_map(model, θ0::Vector{Float64}, scalar::Bool=false)
+    arg(θ) = scalar ? θ[1] : θ                                 # a univariate prior hands the closure a number
+    raw0 = hip_model(model(arg(θ0)))[2]
     raw_from = fill(Int32(-1), length(raw0)); raw_const = copy(raw0)
     for i in eachindex(θ0)
         θp = copy(θ0); θp[i] = 1.25 * θ0[i] + 0.125
-        rawp = hip_model(model(θp))[2]
+        rawp = hip_model(model(arg(θp)))[2]
         for k in eachindex(raw0)
             rawp[k] == raw0[k] && continue
             (rawp[k] == θp[i] && raw0[k] == θ0[i] && raw_from[k] == -1) || return nothing     # not a selection of components
@@ -310,7 +314,7 @@ function HipSampler(θ::Vector, model, prior; seed::UInt64=rand(UInt64), comm=no
     M = length(θ); dθ = length(θ[1])
     comps = prior_components(prior)
     specs = comps === nothing ? nothing : hip_prior.(comps)
-    tmap = infer_theta_map(model, Float64.(collect(θ[1])))
+    tmap = θ[1] isa Number ? infer_theta_map(model, [Float64(θ[1])], true) : infer_theta_map(model, Float64.(collect(θ[1])))
     ok = specs !== nothing && all(!isnothing, specs) && length(specs) == dθ && tmap !== nothing
     fam = ok ? Int32[s[1] for s in specs] : Int32[]
     par = ok ? reduce(hcat, [s[2] for s in specs]) : zeros(5, 0)
@@ -333,7 +337,7 @@ function HipSMC(N::Int64, M::Int64, model::SSM, prior::Sampleable, chain::Int64,
 end
 # SMC(N, M, model, prior, ...) with a product prior (README.md:81-88, examples/inflation_example.jl:58,256): GPU-backed when the
 # closure yields one of the GPU's model families, the reference's own constructor otherwise
-function SMC(N::Int64, M::Int64, model::SSM, prior::Distributions.Product, chain::Int64, ess_threshold::Float64,
+function SMC(N::Int64, M::Int64, model::SSM, prior::MultivariateDistribution, chain::Int64, ess_threshold::Float64,
              min_ar::Float64=-1.0) where SSM
     model(rand(prior)) isa HipModels && return HipSMC(N, M, model, prior, chain, ess_threshold, min_ar)
     return invoke(SMC, Tuple{Int64,Int64,SSM,Sampleable,Int64,Float64,Float64}, N, M, model, prior, chain, ess_threshold, min_ar)
@@ -422,7 +426,8 @@ function rejuvenate_device!(smc::HipSMC, y::Vector{Float64}, ξ::Float64)
         move_seed, θm, logZ, acc, nrun))
     packed = gather(hs, vcat(vec(θm), logZ, Float64.(acc)))         # ONE all-gather of the moved slices
     blk = reshape(packed, per * (dθ + 2), :)
-    smc.θ = [blk[(m - 1) * dθ .+ (1:dθ), r] for r in 1:size(blk, 2) for m in 1:per]
+    smc.θ = eltype(smc.θ) <: Number ? [blk[m, r] for r in 1:size(blk, 2) for m in 1:per] :
+                                      [blk[(m - 1) * dθ .+ (1:dθ), r] for r in 1:size(blk, 2) for m in 1:per]
     smc.logZ = vec(blk[per * dθ .+ (1:per), :])
     return vec(blk[per * (dθ + 1) .+ (1:per), :]) .!= 0.0
 end

@@ -205,7 +205,7 @@ def test_julia_binding_matches_header():
                 r"function smc²!\(smc::HipSMC, y::Vector\{Float64\}, t::Int64, verbose::Bool=true\)",                 # :308
                 r"function expected_parameters\(smc::HipSMC\)",                                                      # :61
                 r"function HipSMC\(N::Int64, M::Int64, model::SSM, prior::Sampleable, chain::Int64, ess_threshold::Float64, min_ar::Float64=-1\.0;",
-                r"function SMC\(N::Int64, M::Int64, model::SSM, prior::Distributions\.Product, chain::Int64, ess_threshold::Float64,",
+                r"function SMC\(N::Int64, M::Int64, model::SSM, prior::MultivariateDistribution, chain::Int64, ess_threshold::Float64,",
                 r"function HipSampler\(θ::Vector, model, prior;",
                 r"function Base\.getproperty\(smc::HipSMC, s::Symbol\)"):
         assert re.search(sig, src), sig
