@@ -1043,7 +1043,11 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
                 Tg[i] = sys_target(sbase, kk[i]);
             } else {   // the block's largest uniform is its break point; the others are iid below it
                 uint64_t pick;
+#if SMC_EXP_PICKF64
+                pick = (uint64_t)(fma((double)(uint32_t)(rr[i] >> 32), 0x1p-32, (double)((uint32_t)rr[i] >> 11) * 0x1p-53) * (double)(Tlast - Tfirst));
+#else
                 mul64wide(rr[i], Tlast - Tfirst, pick, lo_);
+#endif
                 Tg[i] = kk[i] == m_blk - 1 ? Tlast : Tfirst + pick;
             }
             pos[i] = b_lo;

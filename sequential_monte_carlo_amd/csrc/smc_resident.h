@@ -332,8 +332,13 @@ __global__ __launch_bounds__(THREADS, (resident_min_waves<MODEL, THREADS, NP>())
                 for (int k = 0; k < NP; ++k) {
                     const u32x4 rw = draw(v.seed, (uint32_t)(tid + k * THREADS), stream, (uint32_t)t, SLOT_RESAMPLE);
                     uint64_t lo;
+#if SMC_EXP_PICKF64
+                    T2[2 * k] = (uint64_t)(fma((double)rw.v[1], 0x1p-32, (double)(rw.v[0] >> 11) * 0x1p-53) * (double)S);
+                    T2[2 * k + 1] = (uint64_t)(fma((double)rw.v[3], 0x1p-32, (double)(rw.v[2] >> 11) * 0x1p-53) * (double)S);
+#else
                     mul64wide(((uint64_t)rw.v[1] << 32) | rw.v[0], S, T2[2 * k], lo);
                     mul64wide(((uint64_t)rw.v[3] << 32) | rw.v[2], S, T2[2 * k + 1], lo);
+#endif
                 }
             }
             // the search carries the padded position as an LDS byte pointer (one ds_read_b64 with an

@@ -99,9 +99,17 @@ SMC_HD uint32_t xor_and(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// SMC_EXP_ROUNDS / SMC_EXP_PICKF64: timing experiments of `make exp` only (scripts/dbg/exp_spec.sh: what a cheaper numerical
+// specification would buy); the product and the oracle are Philox4x32-10 and 64 x 64 -> 128-bit integer picks
+#ifndef SMC_EXP_ROUNDS
+#define SMC_EXP_ROUNDS 10
+#endif
+#ifndef SMC_EXP_PICKF64
+#define SMC_EXP_PICKF64 0
+#endif
 SMC_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < SMC_EXP_ROUNDS; ++r) {
         // full 32x32 -> 64 products (one v_mad_u64_u32 each on the device)
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
