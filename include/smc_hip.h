@@ -221,7 +221,8 @@ int smc_comm_plan_exchange(const int32_t* a /*[M]*/, int64_t M, int rank, int wo
 /* raw fixed-point weight state (tests): C [n_theta][nseg*seg], m/S/S2hi/S2lo [n_theta][nseg] */
 int smc_get_weights_raw(smc_handle h, uint64_t* C, double* m, uint64_t* S, uint64_t* S2hi, uint64_t* S2lo);
 int smc_get_geometry(smc_handle h, int* seg, int* nseg, int* d, int* resident);
-/* device time (HIP events on the handle's stream) of the last init/step/log_likelihood call */
+/* device time (HIP events on the handle's stream) of the last log_likelihood / step_window call; after smc_init / smc_step (which
+ * place no events on the stream: their results arrive through a ticket in pinned host memory) the host time spent waiting */
 int smc_last_elapsed_ms(smc_handle h, double* ms);
 int smc_synchronize(smc_handle h);
 /* roofline measurement: runs log_likelihood through the one-launch-per-step path and brackets

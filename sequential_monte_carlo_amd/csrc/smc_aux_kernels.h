@@ -300,11 +300,7 @@ __global__ void k_commit(FilterView v, int j, const StepRec* recs /*[ntheta][j]*
     v.last_ess[th] = ess;
     v.last_K[th] = o.kb;
     v.last_D[th] = o.S;
-    if (v.host_out) {
-        v.host_out[th] = z;
-        v.host_out[(size_t)v.ntheta + th] = logmu;
-        v.host_out[2 * (size_t)v.ntheta + th] = ess;
-    }
+    host_emit(v, th, z, logmu, ess);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -93,7 +93,9 @@ struct FilterView {
     double* trace_logmu;     // [T][ntheta] or nullptr
     double* trace_ess;       // [T][ntheta] or nullptr
     const double* y;         // [T] on device (log_likelihood) or nullptr
-    double* host_out;        // pinned host mirror [3][ntheta] of (logZ | last_logmu | last_ess): whoever emits
+    uint32_t host_seq;       // step API: after the three values, their writer stores this ticket in row 3 of host_out (system
+                             // scope release) - the host spins on the pinned words instead of synchronising the stream; 0: no ticket
+    double* host_out;        // pinned host mirror [4][ntheta] of (logZ | last_logmu | last_ess | ticket): whoever emits
                              //    these also stores them here, so the host needs no copy after its stream sync
     int systematic;          // opt-in systematic resampling (SMC_FLAG_SYSTEMATIC): selects the SYS kernels
     double inv_n;            // 1.0 / n  (systematic targets)
@@ -130,6 +132,19 @@ struct FilterView {
 #define SMC_STAMP(v, k) do { } while (0)
 #endif
 // ---- weighted quantiles: helpers shared by the stand-alone kernels (smc_aux_kernels.h) and the per-step summaries --------
+// (logZ, logmu, ess) of filter th into the pinned host mirror; with a ticket (step API) the values are released to the host
+// before the ticket is: the host reads them as soon as it sees the ticket, without a stream synchronisation
+template <class VIEW>
+__device__ __forceinline__ void host_emit(const VIEW& v, int th, double z, double logmu, double ess) {
+    if (!v.host_out) return;
+    v.host_out[th] = z;
+    v.host_out[(size_t)v.ntheta + th] = logmu;
+    v.host_out[2 * (size_t)v.ntheta + th] = ess;
+    if (v.host_seq) {
+        __threadfence_system();
+        __hip_atomic_store(&v.host_out[3 * (size_t)v.ntheta + th], (double)v.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 constexpr int QMAX = 8;      // quantile levels per call
 struct QState {
     uint64_t prefix;         // digits selected so far (high bits of the key)
@@ -501,11 +516,7 @@ __device__ __forceinline__ uint64_t table_prologue(const VIEW& v, int cur, int t
         if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
         const double z = first_emit ? logmu : v.logZ[th] + logmu;
         v.logZ[th] = z;
-        if (v.host_out) {
-            v.host_out[th] = z;
-            v.host_out[(size_t)v.ntheta + th] = logmu;
-            v.host_out[2 * (size_t)v.ntheta + th] = ess;
-        }
+        host_emit(v, th, z, logmu, ess);
     }
     __syncthreads();
     return Dtot;
@@ -725,11 +736,7 @@ __device__ __forceinline__ void emit_own(const VIEW& v, int th, const SegRec& re
     if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
     const double z = first_emit ? logmu : v.logZ[th] + logmu;
     v.logZ[th] = z;
-    if (v.host_out) {
-        v.host_out[th] = z;
-        v.host_out[(size_t)v.ntheta + th] = logmu;
-        v.host_out[2 * (size_t)v.ntheta + th] = ess;
-    }
+    host_emit(v, th, z, logmu, ess);
 }
 
 // (logmu, ess = 0) of the previous step from the totals (K, Dtot) alone: what table_prologue's emit produces when the
@@ -747,11 +754,7 @@ __device__ __forceinline__ void emit_from_totals(const VIEW& v, int th, double K
     if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
     const double z = first_emit ? logmu : v.logZ[th] + logmu;
     v.logZ[th] = z;
-    if (v.host_out) {
-        v.host_out[th] = z;
-        v.host_out[(size_t)v.ntheta + th] = logmu;
-        v.host_out[2 * (size_t)v.ntheta + th] = ess;
-    }
+    host_emit(v, th, z, logmu, ess);
 }
 
 __device__ __forceinline__ double nan_mask() { return bits2d(0x7ff8000000000000ULL); }

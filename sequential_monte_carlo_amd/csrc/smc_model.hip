@@ -129,6 +129,31 @@ hipError_t launch_resident<SMC_MODEL>(const FilterView& v, int T, StepRec* recs,
     return hipErrorInvalidValue;
 }
 
+template <int THREADS, int NP>
+static hipError_t summ_once_t(const FilterView& v, int cur, hipStream_t s) {
+    constexpr int D = model_dim<SMC_MODEL>::value;
+    const size_t lds = summ_once_lds_bytes<D>(2 * NP * THREADS, v.sum_np);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool raised[16] = {};
+    hipError_t e = raise_lds_limit(k_summ_once<THREADS, NP, D>, lds, raised);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_summ_once<THREADS, NP, D>), dim3(v.ntheta), dim3(THREADS), lds, s, v, cur);
+    return hipGetLastError();
+}
+template <>
+hipError_t launch_summ_once<SMC_MODEL>(const FilterView& v, int cur, hipStream_t s) {
+    if (v.nseg != 1) return hipErrorInvalidValue;
+    switch (v.seg) {
+    case 256: return summ_once_t<128, 1>(v, cur, s);
+    case 512: return summ_once_t<256, 1>(v, cur, s);
+    case 1024: return summ_once_t<512, 1>(v, cur, s);
+    case 2048: return summ_once_t<512, 2>(v, cur, s);
+    case 4096: return summ_once_t<512, 4>(v, cur, s);
+    case 8192: return summ_once_t<1024, 4>(v, cur, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <>
 hipError_t launch_window<SMC_MODEL>(const FilterView& v, int T, StepRec* recs, int t0, int bin, int bout, double* win, hipStream_t s) {
     const int np = resident_np(v);

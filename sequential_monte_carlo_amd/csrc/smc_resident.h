@@ -229,6 +229,31 @@ __device__ __forceinline__ void resident_summaries(const FilterView& v, int th, 
     }
 }
 
+// The summaries of the CURRENT state of single-segment filters in one launch (smc_get_quantiles / smc_get_moments between two
+// steps of the README loop, README.md:41,51): state and weights of buffer `cur` into LDS, then the per-step routine above, row 0.
+template <int THREADS, int NP, int D>
+__global__ __launch_bounds__(THREADS) void k_summ_once(FilterView v, int cur) {
+    constexpr int SEG = 2 * NP * THREADS, SEGP = lds_padded_len(SEG);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t* Cs = (uint64_t*)smem;
+    double* xs = (double*)(smem + (size_t)SEGP * 8);
+    uint64_t* sm = (uint64_t*)(smem + (size_t)SEGP * 8 * (1 + D));
+    const int tid = threadIdx.x, th = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int i0 = 2 * (tid + k * THREADS);
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            *reinterpret_cast<double2*>(xs + c * SEGP + lds_pad(i0)) = *reinterpret_cast<const double2*>(v.x[cur] + ((size_t)c * v.ntheta + th) * v.npad + i0);
+        *reinterpret_cast<ulonglong2*>(Cs + lds_pad(i0)) = *reinterpret_cast<const ulonglong2*>(v.C[cur] + (size_t)th * v.npad + i0);
+    }
+    for (int i = tid; i < (int)summary_lds_words(v.sum_np); i += THREADS) sm[i] = 0;
+    __syncthreads();
+    resident_summaries<THREADS, NP, D>(v, th, 0, Cs, xs, SEGP, v.segS[cur][th], sm);
+}
+template <int D>
+__host__ inline size_t summ_once_lds_bytes(int seg, int nq) { return (size_t)lds_padded_len(seg) * 8 * (1 + D) + summary_lds_words(nq) * 8; }
+
 // Window mode (WIN): the same loop over the steps [t0, t0 + T) of filters that already exist (t0 >= 1): the state is
 // read from buffer `bin`, the T steps run in LDS, the state after them goes to buffer `bout`, and (logmu_t, ess_t) of
 // every step go to `win` ([2][T][ntheta], pinned host memory) - nothing else of the handle changes (logZ and the
