@@ -78,6 +78,17 @@ class ThetaComm:
         recv_counts = [int((owners == s).sum()) for s in range(self.world)]
         dest_idx = np.concatenate([np.nonzero(owners == s)[0] for s in range(self.world)]).astype(np.int32)
         sendbuf = self._export(h, np.concatenate(send_idx).astype(np.int32))
+        if sendbuf.is_cuda and self.dist.get_backend() == "gloo":
+            # rehearsal of the N > 1 path on a box with one GPU (several ranks on the same card, `bench.py --dist-backend gloo`,
+            # tests/test_gpu_api.py): gloo moves host memory, so the packed filters are staged through it
+            torch.cuda.synchronize(sendbuf.device)
+            host_send = sendbuf.cpu()
+            host_recv = torch.empty((int(sum(recv_counts)), sendbuf.shape[1]), dtype=sendbuf.dtype)
+            self.dist.all_to_all_single(host_recv, host_send, output_split_sizes=recv_counts, input_split_sizes=send_counts)
+            recvbuf = host_recv.to(sendbuf.device)
+            torch.cuda.synchronize(sendbuf.device)
+            self._import(h, dest_idx, recvbuf)
+            return
         recvbuf = torch.empty((int(sum(recv_counts)), sendbuf.shape[1]), dtype=sendbuf.dtype, device=sendbuf.device)
         self.dist.all_to_all_single(recvbuf, sendbuf, output_split_sizes=recv_counts, input_split_sizes=send_counts)
         if recvbuf.is_cuda:

@@ -2,6 +2,7 @@
 HIP library, checked bit for bit against the same host logic running on the oracle backend."""
 import io
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -574,6 +575,59 @@ def test_per_step_summaries_inside_the_multi_step_calls(ob):
         mm, vv = xs.moments()
         assert s["mean"][t] == pytest.approx(mm, rel=1e-11, abs=1e-13) and s["var"][t] == pytest.approx(vv, rel=1e-8)
     assert s["quantiles"].shape == (30, 3) and s["mean"].shape == (30,)
+
+
+GPU_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch.distributed as dist
+import sequential_monte_carlo_amd as smc
+from sequential_monte_carlo_amd.distributed import ThetaComm
+from test_samplers_cpu import run_dt, run_online
+WS = int(sys.argv[5])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=WS)
+for device in (False, True):
+    tag = sys.argv[4] + (".dev" if device else "")
+    s, stages, _ = run_dt(comm=ThetaComm(dist), device=device, backend=smc.smc_samplers.HipBackend())
+    np.save(tag + ".%d.npy" % dist.get_rank(), np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]]))
+    so, moves, x, w = run_online(M=32, comm=ThetaComm(dist), device=device, window=5 if device else 0, backend=smc.smc_samplers.HipBackend())
+    assert moves >= 1
+    np.save(tag + ".online.%d.npy" % dist.get_rank(), np.concatenate([so.theta.ravel(), so.logZ, so.omega, so.logw, x.ravel(), w.ravel()]))
+dist.destroy_process_group()
+'''
+
+
+def test_theta_sharding_two_ranks_on_one_gpu_gloo(tmp_path):
+    """The N > 1 path with the REAL kernels: two ranks on this box's one GPU (gloo for the collectives, the packed filters staged
+    through host memory - distributed.ThetaComm.exchange_slots), each filtering its half of theta with the library's outer level:
+    density_tempered and the online sampler (host-loop and device rejuvenation, step loop and windows; resample! moves filters
+    between the ranks through smc_pack_slots / smc_unpack_slots) equal the single-process run bit for bit."""
+    import subprocess
+    from test_samplers_cpu import run_dt, run_online
+    script = tmp_path / "worker.py"
+    script.write_text(GPU_GLOO_WORKER)
+    port = str(31500 + (os.getpid() % 2000))
+    world = 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(tmp_path / "out"), str(world)], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    for device in (False, True):
+        tag = str(tmp_path / "out") + (".dev" if device else "")
+        s, stages, _ = run_dt(device=device, backend=smc.smc_samplers.HipBackend())
+        ref = np.concatenate([s.theta.ravel(), s.logZ, [st[0] for st in stages], [s.psteps, s.psteps_skipped]])
+        for r in range(world):
+            assert np.array_equal(np.load(tag + ".%d.npy" % r), ref), device
+        so, moves, x, w = run_online(M=32, device=device, window=5 if device else 0, backend=smc.smc_samplers.HipBackend())
+        head = np.concatenate([so.theta.ravel(), so.logZ, so.omega, so.logw])
+        parts = [np.load(tag + ".online.%d.npy" % r) for r in range(world)]
+        for p_ in parts:
+            assert np.array_equal(p_[:head.size], head), device
+        d, M, N = x.shape[0], x.shape[1], x.shape[2]
+        per = M // world
+        xs = np.concatenate([p_[head.size:head.size + d * per * N].reshape(d, per, N) for p_ in parts], axis=1)
+        ws = np.concatenate([p_[head.size + d * per * N:].reshape(per, N) for p_ in parts], axis=0)
+        assert np.array_equal(xs, x) and np.array_equal(ws, w), device
 
 
 def test_windowed_run_per_period_summaries_on_gpu():

@@ -67,11 +67,11 @@ def _backend(lib_outer=False):
     return b
 
 
-def run_dt(M=32, N=128, T=25, seed=3, comm=None, device=False, lib_outer=False):
+def run_dt(M=32, N=128, T=25, seed=3, comm=None, device=False, lib_outer=False, backend=None):
     """device=True: the sampler gets a ThetaMap, i.e. rejuvenate! takes the one-call-per-rank path (on the GPU:
     smc_pmmh_rejuvenate; here its oracle twin); False: the host loop with numpy random numbers."""
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
-    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=_backend(lib_outer), comm=comm,
+    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=backend or _backend(lib_outer), comm=comm,
                 theta_map=LG_TMAP if device else None)
     assert s.device_pmmh == device
     buf = io.StringIO()
@@ -205,10 +205,10 @@ def test_smc2_online_runs_and_tracks():
     assert -1 < th[0] < 1 and th[1] > 0 and th[2] > 0
 
 
-def run_online(M=24, N=64, T=30, seed=5, comm=None, device=False, window=0, text=None, lib_outer=False):
+def run_online(M=24, N=64, T=30, seed=5, comm=None, device=False, window=0, text=None, lib_outer=False, backend=None):
     """window = 0: the reference's loop, one smc²! per observation; > 0: smc2_run with that many steps per call"""
     _, y = smc.simulate(smc.UnivariateLinearGaussian(**LG), T, seed=1998)
-    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=_backend(lib_outer), comm=comm,
+    s = smc.SMC(N, M, lg_mod, lg_prior(), 2, 0.5, seed=seed, backend=backend or _backend(lib_outer), comm=comm,
                 theta_map=LG_TMAP if device else None)
     smc.smc2(s, y)
     moves = 0
