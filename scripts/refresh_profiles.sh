@@ -7,10 +7,10 @@ COMMIT=${1:-unknown}
 ROUND=${2:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$ROUND; mkdir -p $O
-bash scripts/collect_pmc.sh $COMMIT c2 c4 > $O/pmc.log 2>&1
-cp gpurun_out/pmc_c2.json gpurun_out/pmc_c4.json $O/
+bash scripts/collect_pmc.sh $COMMIT c2 c4 c3 c5 > $O/pmc.log 2>&1
+cp gpurun_out/pmc_c2.json gpurun_out/pmc_c4.json gpurun_out/pmc_c3.json gpurun_out/pmc_c5.json $O/
 # bench reads profiles/pmc_<wl>.json for the counter-derived fields: use the ones just collected
-cp gpurun_out/pmc_c2.json gpurun_out/pmc_c4.json profiles/
+cp gpurun_out/pmc_c2.json gpurun_out/pmc_c4.json gpurun_out/pmc_c3.json gpurun_out/pmc_c5.json profiles/
 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 echo "bench c2 done"
 for wl in c3 c4 c5; do python3 bench.py --workload $wl --no-aux > $O/bench_$wl.json 2> $O/bench_$wl.err; done

@@ -63,38 +63,6 @@ __global__ void k_kalman(const double* raw, int64_t ntheta, const double* y, int
     out[m * 3 + 0] = x; out[m * 3 + 1] = S; out[m * 3 + 2] = logZ;
 }
 
-// filtered moments: sum_i w_i x_i and sum_i w_i x_i^2 per (coordinate, theta).  grid (d, ntheta), one
-// workgroup each; w_i reconstructed from the fixed-point state exactly as k_dense_weights does.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_moments(FilterView v, int cur, double* mean, double* var) {
-    __shared__ double red[2][THREADS / WAVE];
-    const int c = blockIdx.x, th = blockIdx.y, tid = threadIdx.x;
-    const double K = v.last_K[th];
-    const uint64_t Dtot = v.last_D[th];
-    const double Dd = (double)Dtot * pow2i(v.SH - 48);
-    const uint64_t* C = v.C[cur] + (size_t)th * v.npad;
-    const double* x = v.x[cur] + ((size_t)c * v.ntheta + th) * v.npad;
-    double m = 0.0, m2 = 0.0;
-    for (int64_t i = tid; i < v.n; i += THREADS) {
-        const int b = (int)(i / v.seg), j = (int)(i % v.seg);
-        const uint64_t q = C[i] - (j ? C[i - 1] : 0);
-        const double dk = K - v.segk[cur][(size_t)th * v.nseg + b];
-        const double sc = (dk >= 0.0 && dk < 900.0) ? pow2i(-48 - (int)dk) : 0.0;
-        const double w = Dtot ? ((double)q * sc) / Dd : 0.0;
-        m += w * x[i];
-        m2 += w * x[i] * x[i];
-    }
-    for (int d = WAVE / 2; d >= 1; d >>= 1) { m += __shfl_xor(m, d, WAVE); m2 += __shfl_xor(m2, d, WAVE); }
-    if ((tid & (WAVE - 1)) == 0) { red[0][tid / WAVE] = m; red[1][tid / WAVE] = m2; }
-    __syncthreads();
-    if (tid == 0) {
-        double a = 0.0, b2 = 0.0;
-        for (int w = 0; w < THREADS / WAVE; ++w) { a += red[0][w]; b2 += red[1][w]; }
-        mean[(size_t)c * v.ntheta + th] = a;
-        var[(size_t)c * v.ntheta + th] = b2 - a * a;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_breaks: the break points of the resampling steps t0 .. t0+gridDim.x-1 of every filter (smc_spec.h
 // "break points"): F[(tt * ntheta + th) * (nseg + 1) + w], 2^-64 fixed point, F[..][0] = 0.  They depend
@@ -135,88 +103,6 @@ __global__ __launch_bounds__(THREADS) void k_breaks(FilterView v, uint32_t t0, u
     for (int e = 0; e < E; ++e) {
         const int i = tid * E + e;
         if (i < B) out[i + 1] = div_frac64(g[i] + excl, S);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Weighted quantiles of one state coordinate (quantile(x, weights(w), p) of
-// examples/inflation_example.jl:45).  Integer definition (see include/smc_hip.h smc_get_quantiles):
-// W_i = q_i >> sh_b, T = floor(p * sum W); result = smallest value v with sum{W_i : x_i <= v} > T.
-// Radix select on the order-preserving 64-bit key of x, 8 bits per pass: k_qhist accumulates, per
-// requested quantile, the weight histogram of the next digit among the particles that match the
-// digits chosen so far (LDS histograms, 64-bit integer atomics: order-free, hence bit-exact);
-// k_qselect picks the digit in which the running weight passes T.  8 passes, any Nx.
-// ---------------------------------------------------------------------------------------------
-// grid (nwg, ntheta)
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void k_qhist(FilterView v, int cur, int c, int pass, int nq, const QState* st,
-                                                  unsigned long long* hist /*[ntheta][nq][256]*/) {
-    __shared__ unsigned long long lh[QMAX * 256];
-    const int th = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < nq * 256; i += THREADS) lh[i] = 0;
-    uint64_t pref[QMAX];
-#pragma unroll
-    for (int j = 0; j < QMAX; ++j) pref[j] = (j < nq && pass > 0) ? st[(size_t)th * nq + j].prefix : 0;
-    __syncthreads();
-    const double K = v.last_K[th];
-    const uint64_t* C = v.C[cur] + (size_t)th * v.npad;
-    const double* x = v.x[cur] + ((size_t)c * v.ntheta + th) * v.npad;
-    const double* sk = v.segk[cur] + (size_t)th * v.nseg;
-    const int64_t per = (v.n + gridDim.x - 1) / gridDim.x;
-    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < v.n ? i0 + per : v.n;
-    const int hs = 64 - 8 * pass;   // the prefix is key >> hs (pass > 0)
-    for (int64_t i = i0 + tid; i < i1; i += THREADS) {
-        const int b = (int)(i / v.seg), j = (int)(i % v.seg);
-        const int sh = seg_shift(K, sk[b], v.SH);
-        const uint64_t q = C[i] - (j ? C[i - 1] : 0);
-        const uint64_t W = sh < 64 ? q >> sh : 0;
-        if (!W) continue;
-        const uint64_t key = order_key(x[i]);
-        const int bin = (int)((key >> (hs - 8)) & 255);
-#pragma unroll
-        for (int jq = 0; jq < QMAX; ++jq)
-            if (jq < nq && (pass == 0 || (key >> hs) == pref[jq])) atomicAdd(&lh[jq * 256 + bin], (unsigned long long)W);
-    }
-    __syncthreads();
-    for (int i = tid; i < nq * 256; i += THREADS)
-        if (lh[i]) atomicAdd(&hist[(size_t)th * nq * 256 + i], lh[i]);
-}
-
-// grid (nq, ntheta), 256 threads: thread = bin
-__global__ __launch_bounds__(256) void k_qselect(int pass, int nq, const uint64_t* P64, QState* st, unsigned long long* hist,
-                                                 double* out /*[ntheta][nq]*/) {
-    __shared__ uint64_t wt[4];
-    const int jq = blockIdx.x, th = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const size_t sidx = (size_t)th * nq + jq;
-    unsigned long long* hb = hist + sidx * 256;
-    const uint64_t mine = hb[tid];
-    hb[tid] = 0;   // ready for the next pass
-    const uint64_t incl_w = wave_incl_scan(mine, lane);
-    if (lane == WAVE - 1) wt[wave] = incl_w;
-    QState s = st[sidx];
-    __syncthreads();
-    uint64_t off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { off += w < wave ? wt[w] : 0; tot += wt[w]; }
-    const uint64_t incl = off + incl_w, excl = incl - mine;
-    if (pass == 0) {
-        s.prefix = 0;
-        s.below = 0;
-        s.target = tot ? __umul64hi(P64[jq], tot) : ~(uint64_t)0;
-    }
-    __syncthreads();   // every thread has read st[sidx]
-    if (s.target == ~(uint64_t)0) {
-        if (tid == 0) {
-            st[sidx] = s;
-            if (pass == 7) out[sidx] = bits2d(0x7ff8000000000000ULL);
-        }
-        return;
-    }
-    if (mine && s.below + excl <= s.target && s.target < s.below + incl) {   // exactly one bin
-        s.prefix = (s.prefix << 8) | (uint64_t)tid;
-        s.below += excl;
-        st[sidx] = s;
-        if (pass == 7) out[sidx] = key_value(s.prefix);
     }
 }
 

@@ -4,6 +4,7 @@
 #include "../../include/smc_hip.h"
 #include "smc_launch.h"
 #include "smc_aux_kernels.h"
+#include "smc_summ_kernels.h"
 
 #include <atomic>
 #include <chrono>
@@ -51,8 +52,7 @@ struct smc_filter_s {
     StepRec* d_recs = nullptr;
     double* h_pin = nullptr;                   // pinned host mirror [4][ntheta]: logZ | last_logmu | last_ess | ticket of the step API
     uint32_t seq = 0;                          // last ticket handed to a step-API launch
-    uint64_t* d_q = nullptr;                   // scratch of smc_get_quantiles (histograms, select state)
-    size_t qcap = 0;
+    uint64_t* d_ms = nullptr;                  // scratch of the summaries of multi-segment filters (smc_summ_kernels.h) + [ntheta][QMAX] results
     uint64_t* d_brk = nullptr;                 // break points of the steps [v.brk_t0, v.brk_t0 + brk_count)
     uint32_t brk_cap = 0, brk_count = 0;
     int64_t reccap = 0;
@@ -433,7 +433,7 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipFree(h->pm_in);   // pm.theta, pm.logZ, pm.chol, pm.nrun, pm.counts, pm.any live in this block
     (void)hipFree(h->pm.prop); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip); (void)hipFree(h->pm.mask);
     if (h->d_brk) (void)hipFree(h->d_brk);
-    if (h->d_q) (void)hipFree(h->d_q);
+    if (h->d_ms) (void)hipFree(h->d_ms);
     (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
@@ -641,46 +641,48 @@ static void view_summaries(smc_handle h) {
     v.sum_q = h->d_sum_q; v.sum_m = h->d_sum_m;
 }
 // scratch of the radix select: hist [ntheta][np][256] u64 | state [ntheta][np] | P64 [QMAX] | out [ntheta][np]
-static int ensure_qscratch(smc_handle h, int np) {
-    const size_t nst = (size_t)h->v.ntheta * np, words = nst * 256 + nst * 3 + QMAX + nst;
-    if (words > h->qcap) {
-        if (h->d_q) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(h->d_q); h->d_q = nullptr; h->qcap = 0; }
-        HIPCHK(hipMalloc((void**)&h->d_q, words * 8));
-        h->qcap = words;
+// The summaries of the CURRENT weights of filters of any size, enqueued on the handle's stream behind the launch that produced
+// them (no host synchronisation): smc_summ_kernels.h.  q_out [ntheta][np], mean / var [d][ntheta] are device pointers.  The
+// weights must have been emitted (last_K, last_D describe them).
+static int ensure_ms(smc_handle h) {
+    const size_t nth = (size_t)h->v.ntheta, words = ms_words(nth, (size_t)h->v.nseg, (size_t)h->d);
+    if (!h->d_ms) {
+        HIPCHK(hipMalloc((void**)&h->d_ms, (words + nth * QMAX) * 8));
+        HIPCHK(hipMemsetAsync(h->d_ms, 0, (words + nth * QMAX) * 8, h->stream));
     }
     return SMC_OK;
 }
-// The summaries of the CURRENT weights of a filter of any size into row `row` of the traces, enqueued on the handle's stream
-// behind the step that produced them (no host synchronisation): the stand-alone kernels of smc_get_quantiles /
-// smc_get_moments.  The weights must have been emitted (last_K, last_D describe them).
-static int enqueue_step_summaries(smc_handle h, int64_t row) {
+static int enqueue_ms(smc_handle h, int component, int np, const uint64_t* p64, bool mom, double* q_out, double* mean, double* var) {
     const size_t nth = (size_t)h->v.ntheta;
-    if (h->sum_np > 0) {
-        const int np = h->sum_np;
-        const size_t nst = nth * np;
-        int rc = ensure_qscratch(h, np);
-        if (rc) return rc;
-        uint64_t* buf = h->d_q;
-        unsigned long long* hist = (unsigned long long*)buf;
-        QState* st = (QState*)(buf + nst * 256);
-        uint64_t* P64 = buf + nst * 256 + nst * 3;
-        HIPCHK(hipMemsetAsync(buf, 0, (nst * 256 + nst * 3) * 8, h->stream));
-        HIPCHK(hipMemcpyAsync(P64, h->sum_p64, sizeof h->sum_p64, hipMemcpyHostToDevice, h->stream));
-        int nwg = (int)((h->v.n + 4095) / 4096);
-        nwg = nwg > 256 ? 256 : nwg;
-        for (int pass = 0; pass < 8; ++pass) {
-            hipLaunchKernelGGL((k_qhist<256>), dim3(nwg, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, h->sum_comp, pass, np, st, hist);
-            hipLaunchKernelGGL(k_qselect, dim3(np, h->v.ntheta), dim3(256), 0, h->stream, pass, np, P64, st, hist, h->d_sum_q + (size_t)row * nst);
-        }
-        HIPCHK(hipGetLastError());
+    int rc = ensure_ms(h);
+    if (rc) return rc;
+    const MsScratch ms = ms_carve(h->d_ms, nth, (size_t)h->v.nseg, (size_t)h->d);
+    FilterView v = h->v;
+    v.sum_np = np; v.sum_comp = np > 0 ? component : 0; v.sum_mom = mom ? 1 : 0;
+    for (int j = 0; j < QMAX; ++j) v.sum_p64[j] = j < np ? p64[j] : 0;
+    // streaming kernels: workgroups of 1024 threads over consecutive segments - about 256 workgroups in all for the passes that
+    // only read, about 64 for the histogram (every workgroup flushes its occupied bins with device-scope atomics)
+    auto groups = [&](int want) {
+        int g = want / h->v.ntheta;
+        g = g < 1 ? 1 : g;
+        return g > h->v.nseg ? h->v.nseg : g;
+    };
+    const int g_read = groups(256), g_hist = groups(64);
+    hipLaunchKernelGGL(k_ms_range, dim3(g_read, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, h->d, ms);
+    if (np > 0) hipLaunchKernelGGL(k_ms_hist, dim3(g_hist, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, g_read, ms);
+    hipLaunchKernelGGL(k_ms_pick, dim3(h->v.ntheta), dim3(MS_THREADS), 0, h->stream, v, h->d, g_read, ms, q_out, mean, var);
+    if (np > 0) {
+        hipLaunchKernelGGL(k_ms_collect, dim3(g_read, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, ms);
+        hipLaunchKernelGGL(k_ms_select, dim3(np, h->v.ntheta), dim3(MS_SEL_THREADS), 0, h->stream, v, h->cur, ms, q_out);
     }
-    if (h->sum_mom) {
-        const size_t nout = (size_t)h->d * nth;
-        double* base = h->d_sum_m + (size_t)row * 2 * nout;
-        hipLaunchKernelGGL((k_moments<256>), dim3(h->d, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, base, base + nout);
-        HIPCHK(hipGetLastError());
-    }
+    HIPCHK(hipGetLastError());
     return SMC_OK;
+}
+// ... into row `row` of the traces of a multi-step call
+static int enqueue_step_summaries(smc_handle h, int64_t row) {
+    const size_t nth = (size_t)h->v.ntheta, nout = (size_t)h->d * nth;
+    double* mbase = h->d_sum_m + (size_t)row * 2 * nout;
+    return enqueue_ms(h, h->sum_comp, h->sum_np, h->sum_p64, h->sum_mom != 0, h->d_sum_q + (size_t)row * nth * h->sum_np, mbase, mbase + nout);
 }
 
 extern "C" int smc_set_summaries(smc_handle h, int component, const double* p, int np, int moments) {
@@ -1444,8 +1446,7 @@ extern "C" int smc_get_moments(smc_handle h, double* mean, double* var) {
     const size_t nout = (size_t)h->d * h->v.ntheta;
     if (!h->d_wdense) HIPCHK(dalloc(&h->d_wdense, (size_t)h->v.ntheta * h->v.n + 2 * nout));
     double *d_mean = h->d_wdense, *d_var = h->d_wdense + nout;
-    hipLaunchKernelGGL((k_moments<256>), dim3(h->d, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, d_mean, d_var);
-    HIPCHK(hipGetLastError());
+    if ((rc = enqueue_ms(h, 0, 0, nullptr, true, nullptr, d_mean, d_var))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(mean, d_mean, nout * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(var, d_var, nout * 8, hipMemcpyDeviceToHost));
@@ -1463,26 +1464,13 @@ extern "C" int smc_get_quantiles(smc_handle h, int component, const double* p, i
     bool done = false;
     if ((rc = summaries_once(h, component, p, np, false, out, nullptr, nullptr, done)) || done) return rc;
     const size_t nth = (size_t)h->v.ntheta, nst = nth * np;
-    if ((rc = ensure_qscratch(h, np))) return rc;   // scratch kept with the handle: the README loop asks for quantiles every step
-    uint64_t* buf = h->d_q;
-    unsigned long long* hist = (unsigned long long*)buf;
-    QState* st = (QState*)(buf + nst * 256);
-    uint64_t* P64 = buf + nst * 256 + nst * 3;
-    double* d_out = (double*)(P64 + QMAX);
     uint64_t hp[QMAX];
     for (int j = 0; j < QMAX; ++j) hp[j] = j < np ? prob_to_u64(p[j]) : 0;
-    hipError_t e = hipMemsetAsync(buf, 0, (nst * 256 + nst * 3) * 8, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(P64, hp, sizeof hp, hipMemcpyHostToDevice, h->stream);
-    int nwg = (int)((h->v.n + 4095) / 4096);
-    nwg = nwg > 256 ? 256 : nwg;
-    for (int pass = 0; pass < 8 && e == hipSuccess; ++pass) {
-        hipLaunchKernelGGL((k_qhist<256>), dim3(nwg, h->v.ntheta), dim3(256), 0, h->stream, h->v, h->cur, component, pass, np, st, hist);
-        hipLaunchKernelGGL(k_qselect, dim3(np, h->v.ntheta), dim3(256), 0, h->stream, pass, np, P64, st, hist, d_out);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, d_out, nst * 8, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return fail(SMC_EHIP, hipGetErrorString(e));
+    if ((rc = ensure_ms(h))) return rc;
+    double* d_out = (double*)(h->d_ms + ms_words(nth, (size_t)h->v.nseg, (size_t)h->d));
+    if ((rc = enqueue_ms(h, component, np, hp, false, d_out, nullptr, nullptr))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, d_out, nst * 8, hipMemcpyDeviceToHost));
     return SMC_OK;
 }
 

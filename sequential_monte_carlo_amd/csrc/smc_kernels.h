@@ -146,11 +146,6 @@ __device__ __forceinline__ void host_emit(const VIEW& v, int th, double z, doubl
     }
 }
 constexpr int QMAX = 8;      // quantile levels per call
-struct QState {
-    uint64_t prefix;         // digits selected so far (high bits of the key)
-    uint64_t below;          // weight of all keys below the prefix
-    uint64_t target;         // T; ~0 marks a filter whose weights are all zero
-};
 __host__ __device__ inline uint64_t order_key(double x) {
     const uint64_t b = d2bits(x);
     return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
