@@ -500,9 +500,14 @@ def test_per_step_summaries_inside_the_multi_step_calls(ob):
     # LGC / LGZ: the selection's fallback paths - clusters of nearly / exactly equal values (state noise 1e-12 resp. none under
     # a sharp likelihood: more than 64 weighted particles in one value bin; with no noise the cloud ends up as ONE value)
     LGC, LGZ = [0.5, 1.0, 1e-24, 0.01, 0.0, 1.0], [0.5, 1.0, 0.0, 0.01, 0.0, 1.0]
+    LGE = [0.5, 1.0, 0.0, 0.01, 0.3, 0.0]   # no noise at all: every particle holds the same value at every step (no range to bin)
     cases = ((1, LGR, 1024, 0, 3, 0, 0), (1, LGR, 1000, 0, 2, 0, 0), (3, UCR, 512, 0, 2, 2, 0), (3, UCR, 2048, 0, 1, 0, 0), (2, SVR, 4096, 0, 2, 0, 0),
              (1, LGR, 8192, 0, 1, 0, 0), (1, LGC, 1024, 0, 2, 0, 0), (1, LGZ, 1024, 0, 2, 0, 0), (1, LGZ, 2048, 0, 1, 0, 0),
-             (1, LGR, 5000, 1024, 2, 0, 0), (3, UCR, 3000, 512, 1, 1, 0), (1, LGR, 1024, 0, 2, 0, L.FLAG_SYSTEMATIC))
+             (1, LGR, 5000, 1024, 2, 0, 0), (3, UCR, 3000, 512, 1, 1, 0), (1, LGR, 1024, 0, 2, 0, L.FLAG_SYSTEMATIC),
+             # several segments (csrc/smc_summ_kernels.h) and its fallbacks: clusters of equal values overflow a bin's candidate
+             # list, a cloud of ONE value has no range (both: the radix select streams over the whole filter); 2^17 particles
+             (1, LGZ, 9000, 1024, 1, 0, 0), (1, LGC, 9000, 2048, 2, 0, 0), (1, LGR, 2**17, 0, 1, 0, 0),
+             (1, LGE, 1024, 0, 1, 0, 0), (1, LGE, 5000, 1024, 1, 0, 0))
     for model, raw, n, seg, nth, comp, flags in cases:
         T = 12
         _, y = ob.simulate(model, LGR if model == 1 else raw, T, 5)
