@@ -148,6 +148,25 @@ function log_likelihood(N::Int64, y::Vector{Float64}, model::HipModels)
     return HipParticles(f, 1), HipWeights(f, 1), logZ[]
 end
 
+# the README loop (README.md:33-61: bootstrap_filter!, then quantile(x, ...) at every observation) as ONE call: the weighted
+# quantiles of state coordinate `component` (0-based) at the levels p and / or mean and variance of every coordinate after
+# every step, recorded on the device inside the filter loop -> (x, w, logZ, q [np x T], mean [d x T], var [d x T])
+function log_likelihood(N::Int64, y::Vector{Float64}, model::HipModels, p::Vector{Float64}; component::Int=0, moments::Bool=true)
+    f = set_models!(HipFilter(hip_model(model)[1], 1, N), [model])
+    T = length(y); logZ = Ref{Float64}()
+    GC.@preserve p smc_check(ccall((:smc_set_summaries, LIBSMC), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Cint),
+                                    f.h, component, p, length(p), moments ? 1 : 0))
+    GC.@preserve y smc_check(ccall((:smc_log_likelihood, LIBSMC), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        f.h, y, T, logZ, C_NULL, C_NULL))
+    q = Matrix{Float64}(undef, length(p), T); mean = Matrix{Float64}(undef, f.d, T); var = Matrix{Float64}(undef, f.d, T)
+    GC.@preserve q mean var smc_check(ccall((:smc_get_summaries, LIBSMC), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        f.h, T, isempty(p) ? C_NULL : pointer(q), moments ? pointer(mean) : C_NULL, moments ? pointer(var) : C_NULL))
+    smc_check(ccall((:smc_set_summaries, LIBSMC), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Cint), f.h, 0, C_NULL, 0, 0))
+    return HipParticles(f, 1), HipWeights(f, 1), logZ[], q, mean, var
+end
+
 # batched: what the Threads.@threads loops of smc_samplers.jl:112-121,174-180,223-229 become -- ONE call.
 # Returns the handle too (its slot m is smc.x[m], smc.w[m]).  skip[m] != 0: filter m is not run, logZ[m] = -Inf (:116).
 function log_likelihood(N::Int64, y::Vector{Float64}, models::Vector{<:HipModels}; seed::UInt64=rand(UInt64), f=nothing,
