@@ -640,7 +640,6 @@ static void view_summaries(smc_handle h) {
     for (int j = 0; j < QMAX; ++j) v.sum_p64[j] = h->sum_p64[j];
     v.sum_q = h->d_sum_q; v.sum_m = h->d_sum_m;
 }
-// scratch of the radix select: hist [ntheta][np][256] u64 | state [ntheta][np] | P64 [QMAX] | out [ntheta][np]
 // The summaries of the CURRENT weights of filters of any size, enqueued on the handle's stream behind the launch that produced
 // them (no host synchronisation): smc_summ_kernels.h.  q_out [ntheta][np], mean / var [d][ntheta] are device pointers.  The
 // weights must have been emitted (last_K, last_D describe them).

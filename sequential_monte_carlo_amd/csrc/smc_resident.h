@@ -35,7 +35,7 @@ __host__ __device__ inline size_t resident_lds_bytes(int seg, int threads, int n
 //              particles of that bin are collected and ranked inside the wave - four barriers.  Whenever that does not apply
 //              (a non-finite value carrying weight, an empty or overflowing range, more than 64 particles in a chosen bin) the
 //              step falls back to the 8-pass radix select on the order-preserving key, one wave per level picking the digit;
-//   moments:   sum w x and sum w x^2 with the dense weights w = q 2^-48 / (S 2^-48) of k_moments.
+//   moments:   sum w x and sum w x^2 with the dense weights w = q 2^-48 / (S 2^-48) (smc_get_state's w).
 // Called by every thread of the workgroup after the step's last barrier; ends with the histograms cleared for the next step.
 template <int THREADS, int NP, int D>
 __device__ __forceinline__ void resident_summaries(const FilterView& v, int th, int64_t row, const uint64_t* Cs, const double* xs, int SEGP,
