@@ -662,8 +662,8 @@ typedef struct {
 void orc_filter_set_systematic(orc_filter* f, int on) { f->systematic = on ? 1 : 0; }
 
 int orc_auto_seg(int64_t n) {   /* the same rule as smc_auto_seg (the segment length is part of the spec) */
-    if (n > ((int64_t)1 << 24)) return 8192;
-    if (n > ((int64_t)1 << 21)) return 4096;
+    if (n > (int64_t)16384 * 4096) return 8192;   /* at most 16384 segments */
+    if (n > (int64_t)16384 * 2048) return 4096;
     if (n > ((int64_t)1 << 19)) return 2048;
     if (n > ((int64_t)1 << 17)) return 1024;
     if (n > ((int64_t)1 << 15)) return 512;

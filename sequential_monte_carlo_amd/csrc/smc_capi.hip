@@ -115,15 +115,19 @@ bool geo_default(int seg, Geo& g) {
 }
 }  // namespace smc
 
+// most segments a filter may have (the break points of a step sit in the LDS of k_breaks: 8 B per segment)
+constexpr int MAX_NSEG = 16384;
 extern "C" int smc_auto_seg(int64_t n) {
-    // measured (scripts/nx_sweep.py, scripts/dbg/mid_sizes.py): one segment up to 2048 particles; above, the SHORTEST segment
-    // whose workgroup still has a thread per segment (nseg <= seg / 2 resp. 512: the one-record-per-thread table prologue) -
-    // a filter of 2^14..2^18 particles is a handful of workgroups on a 256-CU chip and bound by the life of ONE of them, which
-    // shorter segments (fewer particles per workgroup) cut from 9.4 to 6.0-7.3 us per step; 2048 up to 2^21 particles; beyond
-    // that the per-workgroup segment tables (16 B per segment in LDS) cost occupancy and 4096 wins; 8192 keeps nseg <= 4096 up
-    // to 2^25.  The segment length is part of the numerical spec (the CPU restatement used by the tests follows the same rule).
-    if (n > ((int64_t)1 << 24)) return 8192;
-    if (n > ((int64_t)1 << 21)) return 4096;
+    // measured (scripts/nx_sweep.py, scripts/dbg/mid_sizes.py): one segment up to 8192 particles (the batched callers' shape, LDS-
+    // resident); above, the SHORTEST segment whose workgroup still has a thread per segment (nseg <= seg / 2 resp. 512: the
+    // one-record-per-thread window prologue) - a filter of 2^14..2^18 particles is a handful of workgroups on a 256-CU chip and
+    // bound by the life of ONE of them, which shorter segments (fewer particles per workgroup) cut from 9.4 to 6.0-7.3 us per
+    // step; 2048 (512 threads x two pairs: the fastest geometry, 12.5 us per 2^20 particles) from 2^19 particles on for as long
+    // as the segment count allows (2^25 particles) - beyond 512 segments the table of the segments is built once per step by
+    // k_table instead of by every workgroup; 4096 / 8192 keep the count at MAX_NSEG up to 2^26 / 2^27 particles.  The segment
+    // length is part of the numerical spec (the CPU restatement used by the tests follows the same rule).
+    if (n > (int64_t)MAX_NSEG * 4096) return 8192;
+    if (n > (int64_t)MAX_NSEG * 2048) return 4096;
     if (n > ((int64_t)1 << 19)) return 2048;
     if (n > ((int64_t)1 << 17)) return 1024;
     if (n > ((int64_t)1 << 15)) return 512;
@@ -151,7 +155,19 @@ static hipError_t do_init(smc_filter_s* h, double y) {
     }
     return hipErrorInvalidValue;
 }
+// filters with more segments than threads per workgroup (v.tabD): the segment table of the current weights, built once (k_table;
+// emit as k_step's emit_prev: 0 nothing, 1 (logmu, ess) from the full records, 2 from the totals)
+static hipError_t do_table(smc_filter_s* h, int emit, int first_emit, uint32_t t_emit) {
+    constexpr int TH = 1024;
+    hipLaunchKernelGGL((k_table<TH>), dim3(h->v.ntheta), dim3(TH), scr_words(TH, 1) * 8, h->stream, h->v, h->cur, emit, first_emit, t_emit);
+    return hipGetLastError();
+}
 static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) {
+    if (h->v.tabD) {
+        hipError_t e = do_table(h, emit_prev, t == 1u ? 1 : 0, t - 1u);
+        if (e != hipSuccess) return e;
+        emit_prev = 0;
+    }
     switch (h->model) {
     case MODEL_LG1D: return launch_step<MODEL_LG1D>(h->v, h->geo, h->cur, t, emit_prev, y, h->stream);
     case MODEL_SV1D: return launch_step<MODEL_SV1D>(h->v, h->geo, h->cur, t, emit_prev, y, h->stream);
@@ -178,7 +194,19 @@ static hipError_t ensure_breaks(smc_filter_s* h, uint32_t t, uint32_t t_end) {
     uint32_t cnt = t_end > t ? t_end - t : 1;                  // no further than the caller will go
     cnt = cnt > h->brk_cap ? h->brk_cap : cnt;
     constexpr int TH = 256;
-    hipLaunchKernelGGL((k_breaks<TH>), dim3(cnt, v.ntheta), dim3(TH), ((size_t)v.nseg + 1 + TH / WAVE) * 8, h->stream, v, t, h->d_brk);
+    const size_t lds = ((size_t)v.nseg + 1 + TH / WAVE) * 8;
+    if (lds > 64 * 1024) {   // filters of more than 8187 segments: beyond the default limit of dynamic LDS
+        static bool raised[16] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 16 || !raised[dev]) {
+            e = hipFuncSetAttribute((const void*)k_breaks<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 16) raised[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((k_breaks<TH>), dim3(cnt, v.ntheta), dim3(TH), lds, h->stream, v, t, h->d_brk);
     v.brk_t0 = t;
     h->brk_count = cnt;
     return hipGetLastError();
@@ -210,6 +238,7 @@ static hipError_t do_window(smc_filter_s* h, int k, int bout) {
 }
 
 static hipError_t do_finalize(smc_filter_s* h, int first_emit, uint32_t t_emit) {
+    if (h->v.tabD) return do_table(h, 1, first_emit, t_emit);   // (no room in LDS for a table of that many segments)
     constexpr int TH = 256;
     const size_t lds = table_lds_bytes(h->v.nseg_p2, TH, 1);
     hipLaunchKernelGGL((k_finalize<TH>), dim3(h->v.ntheta), dim3(TH), lds, h->stream, h->v, h->cur, first_emit, t_emit);
@@ -241,7 +270,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
         if (geo_valid(seg, atoi(e), g2)) g = g2;
     }
     const int64_t nseg = (n_x + seg - 1) / seg;
-    if (nseg > 4096) return fail(SMC_EINVAL, "smc_create: more than 4096 segments; use a larger seg");
+    if (nseg > MAX_NSEG) return fail(SMC_EINVAL, "smc_create: more than 16384 segments; use a larger seg");
     if (n_x > ((int64_t)1 << 31)) return fail(SMC_EINVAL, "smc_create: n_x > 2^31");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
@@ -303,6 +332,10 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     TRY(dalloc(&v.last_ess, nt));
     TRY(dalloc(&v.last_K, nt));
     TRY(dalloc(&v.last_D, nt));
+    if (v.nseg_p2 > g.threads) {   // more segments than a workgroup has threads: the segment table is built once per step (k_table)
+        TRY(dalloc(&v.tabD, nt * (size_t)v.nseg_p2));
+        TRY(dalloc(&v.tabsh, nt * (size_t)v.nseg_p2));
+    }
     TRY(hipHostMalloc((void**)&h->h_pin, 4 * nt * 8, hipHostMallocDefault));   // coherent, device-visible
     memset(h->h_pin, 0, 4 * nt * 8);
     v.host_out = h->h_pin;
@@ -434,7 +467,7 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipFree(h->pm.prop); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip); (void)hipFree(h->pm.mask);
     if (h->d_brk) (void)hipFree(h->d_brk);
     if (h->d_ms) (void)hipFree(h->d_ms);
-    (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D);
+    (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D); (void)hipFree(v.tabD); (void)hipFree(v.tabsh);
     (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
     (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m); (void)hipFree(h->d_pflags);

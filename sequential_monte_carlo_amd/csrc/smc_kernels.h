@@ -93,6 +93,9 @@ struct FilterView {
     double* trace_logmu;     // [T][ntheta] or nullptr
     double* trace_ess;       // [T][ntheta] or nullptr
     const double* y;         // [T] on device (log_likelihood) or nullptr
+    uint64_t* tabD;          // filters with more segments than a workgroup has threads: the segment table of the weights being
+    int* tabsh;              // resampled, built ONCE per step by k_table ([ntheta][nseg_p2] inclusive sums / shifts) instead of by every
+                             // workgroup of k_step (nseg^2 record reads and a table in LDS per workgroup); nullptr otherwise
     uint32_t host_seq;       // step API: after the three values, their writer stores this ticket in row 3 of host_out (system
                              // scope release) - the host spins on the pinned words instead of synchronising the stream; 0: no ticket
     double* host_out;        // pinned host mirror [4][ntheta] of (logZ | last_logmu | last_ess | ticket): whoever emits
@@ -429,7 +432,7 @@ __device__ __forceinline__ TablePre table_preload(const VIEW& v, int cur, int th
 }
 template <int THREADS, class VIEW>
 __device__ __forceinline__ uint64_t table_prologue(const VIEW& v, int cur, int th, const TableLds& L, bool emit,
-                                                   bool first_emit, uint32_t t_emit, const TablePre* pre = nullptr) {
+                                                   bool first_emit, uint32_t t_emit, const TablePre* pre = nullptr, double* Kout = nullptr) {
     constexpr int NW = THREADS / WAVE;
     const int tid = smc_tid(), lane = tid & (WAVE - 1), wave = tid / WAVE;
     const size_t base = (size_t)th * v.nseg;
@@ -450,6 +453,7 @@ __device__ __forceinline__ uint64_t table_prologue(const VIEW& v, int cur, int t
         const int km = block_max_i32<THREADS>(ki, (int*)red);
         K = km == DEADK ? -inf() : (double)km;
     }
+    if (Kout) *Kout = K;
 
     // blocked layout: thread owns E consecutive table entries
     const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1;
@@ -834,8 +838,11 @@ __host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int n
 // PERSIST: the body as one iteration of the persistent step kernel (k_persist below): every store another workgroup of the
 // same launch reads (x, C, the segment record) is a write-through store; the loads are plain - the caller has polled the
 // previous step's completion flags and made an agent-scope acquire before the call.
-template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS, bool PERSIST, class VIEW>
+// GTAB: the segment table comes from global memory (v.tabD, v.tabsh; k_table built it before this launch and emitted the previous
+// step): filters with more segments than the workgroup has threads.  No table in LDS, no emission here.
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS, bool PERSIST, class VIEW, bool GTAB = false>
 __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, int emit_prev, double yval, char* smem) {
+    static_assert(!GTAB || (MULTI && !PERSIST), "global table: multi-segment launches");
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
     constexpr int NQ = 2 * NP;   // particles per thread
@@ -874,7 +881,7 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         F0 = Fb[0];
         F1 = Fb[1];
     }
-    const TablePre tpre = MULTI ? table_preload<THREADS>(v, cur, th, emit_prev && sb == 0) : TablePre{-inf(), 0, 0, 0};
+    const TablePre tpre = (MULTI && !GTAB) ? table_preload<THREADS>(v, cur, th, emit_prev && sb == 0) : TablePre{-inf(), 0, 0, 0};
     // (2) the 64-bit pick numbers of this thread's children
     uint64_t rr[NQ];
 #pragma unroll
@@ -949,8 +956,13 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
     int bseg[NQ];
     uint64_t* Cst = nullptr;   // staged segments [NSTAGE][SEG] (MULTI)
     int blo = 0;
+    const int tab_p2 = GTAB ? 0 : v.nseg_p2;   // table entries in LDS
     if (MULTI) {
-        const TableLds L = carve(smem, v.nseg_p2);
+        TableLds L = carve(smem, tab_p2);
+        if (GTAB) {
+            L.Dcum = v.tabD + (size_t)th * v.nseg_p2;
+            L.sh = v.tabsh + (size_t)th * v.nseg_p2;
+        }
         scr = L.scr;
         // systematic: the step's one uniform, drawn by ONE thread (75 VALU instructions the other waves do
         // not spend) and published through LDS across the barriers of the table prologue
@@ -968,10 +980,18 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         const bool emitter = emit_prev && sb == 0;
         const bool emit_totals = emitter && emit_prev == 2;
         const int s_hi = spec_lo + NSTAGE - 1 < v.nseg - 1 ? spec_lo + NSTAGE - 1 : v.nseg - 1;
-        const bool use_fast = SPEC && (!emitter || emit_totals) && v.nseg_p2 <= THREADS;      // workgroup-uniform
+        const bool use_fast = SPEC && (GTAB || ((!emitter || emit_totals) && v.nseg_p2 <= THREADS));      // workgroup-uniform
         uint64_t P0 = 0, Dc[NSTAGE];
         int shw[NSTAGE];
-        if (use_fast) {
+        if (GTAB) {   // the table exists: the total and, for the speculative window, its entries (nseg > THREADS >= NSTAGE)
+            alive = L.Dcum[v.nseg - 1];
+            if (SPEC) {
+                P0 = spec_lo ? L.Dcum[spec_lo - 1] : 0;
+#pragma unroll
+                for (int i = 0; i < NSTAGE; ++i) { Dc[i] = L.Dcum[spec_lo + i]; shw[i] = L.sh[spec_lo + i]; }
+            }
+            if (SYS) __syncthreads();   // (the step's uniform in LDS: the prologues' barriers otherwise)
+        } else if (use_fast) {
             double Kw;
             alive = window_prologue<THREADS, NSTAGE>(v, L.scr, tpre, spec_lo, P0, Dc, shw, Kw);
             if (emit_totals && tid == 0) emit_from_totals(v, th, Kw, alive, t == 1u, t - 1u);
@@ -997,7 +1017,7 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         bool fast = false;
         if (use_fast) {
             fast = (spec_lo == 0 || P0 <= Tfirst) && Tlast < Dc[s_hi - spec_lo];
-            if (!fast) alive = table_prologue<THREADS>(v, cur, th, L, false, false, 0u, &tpre);   // rare: very uneven weights
+            if (!fast && !GTAB) alive = table_prologue<THREADS>(v, cur, th, L, false, false, 0u, &tpre);   // rare: very uneven weights
         }
         int b_lo = 0, b_hi = 0;
         if (fast || (SPEC && !use_fast && (spec_lo == 0 || L.Dcum[spec_lo - 1] <= Tfirst) && Tlast < L.Dcum[s_hi])) {
@@ -1014,7 +1034,7 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         }
         int w0 = 1;
         while (w0 < b_hi - b_lo + 1) w0 <<= 1;
-        Cst = (uint64_t*)(smem + (size_t)v.nseg_p2 * 16 + scr_words(THREADS, NP) * 8);
+        Cst = (uint64_t*)(smem + (size_t)tab_p2 * 16 + scr_words(THREADS, NP) * 8);
         // the staged window: the speculative one if it covers the range, else (re)load from b_lo -
         // 16 B per lane, coalesced; the data lands in LDS after the normals have been computed
         const bool spec_ok = SPEC && b_lo >= spec_lo && b_hi < spec_lo + NSTAGE;
@@ -1257,10 +1277,10 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
     SMC_STAMP(v, 7);
 }
 
-template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false>
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false, bool GTAB = false>
 __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_t t, int emit_prev, double yval) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    step_body<MODEL, THREADS, NP, MULTI, SYS, false>(v, cur, t, emit_prev, yval, smem);
+    step_body<MODEL, THREADS, NP, MULTI, SYS, false, FilterView, GTAB>(v, cur, t, emit_prev, yval, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1346,6 +1366,28 @@ __global__ __launch_bounds__(THREADS) void k_finalize(FilterView v, int cur, int
     }
     const TableLds L = carve(smem, v.nseg_p2);
     table_prologue<THREADS>(v, cur, blockIdx.x, L, true, first_emit != 0, t_emit);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_table : the segment table of the weights in buffer `cur` into global memory (v.tabD, v.tabsh), ONCE per step, for filters
+// with more segments than a workgroup of k_step has threads (k_step<..., GTAB> then reads its window and the total instead of
+// every workgroup rebuilding the table from all records: nseg^2 record reads per step and 16 B of LDS per segment in every
+// workgroup - the reason filters beyond 2^20 particles ran at half the rate).  The same integers table_prologue puts in LDS.
+// emit: 0 nothing; 1 (logmu, ess) of these weights from the full records; 2 (logmu, ess = 0) from the totals (the records carry
+// no sum of squares).  grid (ntheta)
+// ---------------------------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_table(FilterView v, int cur, int emit, int first_emit, uint32_t t_emit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int th = blockIdx.x;
+    if (v.skip && v.skip[th]) return;
+    TableLds L;
+    L.Dcum = v.tabD + (size_t)th * v.nseg_p2;
+    L.sh = v.tabsh + (size_t)th * v.nseg_p2;
+    L.scr = (uint64_t*)smem;
+    double K;
+    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit == 1, first_emit != 0, t_emit, nullptr, &K);
+    if (emit == 2 && threadIdx.x == 0) emit_from_totals(v, th, K, Dtot, first_emit != 0, t_emit);
 }
 
 }  // namespace smc

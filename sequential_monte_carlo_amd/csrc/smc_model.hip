@@ -31,6 +31,14 @@ static hipError_t init_t(const FilterView& v, int nxt, double y, hipStream_t s) 
 }
 template <int THREADS, int NP, bool SYS>
 static hipError_t step_sys_t(const FilterView& v, int cur, uint32_t t, int emit_prev, double y, hipStream_t s) {
+    if (v.tabD) {   // the table comes from k_table (launched by the caller before this step): no table in LDS, nothing to emit
+        const size_t lds = step_lds_bytes(0, THREADS, NP, true);
+        static bool raised[16] = {};
+        hipError_t e = raise_lds_limit(k_step<SMC_MODEL, THREADS, NP, true, SYS, true>, lds, raised);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, true, SYS, true>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t, 0, y);
+        return hipGetLastError();
+    }
     const size_t lds = step_lds_bytes(v.nseg_p2, THREADS, NP, v.nseg > 1);
     {
         static bool raised[2][16] = {};   // per instantiation, variant and device

@@ -476,6 +476,76 @@ def test_many_segments_per_thread_bit_exact(L, ob):
         h.close()
 
 
+def test_global_segment_table_paths(L, ob):
+    """Filters with more segments than a workgroup has threads take the segment table from global memory (k_table builds it once
+    per step, k_step<..., GTAB> reads its window and the total): without traces (the previous step emitted from the totals), with
+    them, batches with distinct parameters, three state coordinates, ragged sizes, wildly uneven weights (targets outside the
+    speculative window: the searches walk the GLOBAL table), the systematic resampler, the step API with a permutation in between -
+    bit-exact against the oracle every way."""
+    # (model, raw, n, seg, ntheta, flags)
+    UC = RAW[3]
+    cases = ((1, LG, 40000, 256, 2, 0), (3, UC, 33000, 256, 1, 0), (1, [0.9, 1.0, 1.0, 1e-6, 0.0, 4.0], 60000, 256, 1, 0),
+             (1, LG, 300 * 512 - 5, 512, 1, L.FLAG_SYSTEMATIC), (2, SV, 1030 * 1024, 1024, 1, 0))
+    for model, raw, n, seg, nth, flags in cases:
+        T = 6 if n < 500000 else 3
+        _, y = ob.simulate(model, RAW[model], T, 11)
+        raws = np.tile(raw, (nth, 1))
+        if nth > 1:
+            raws[1, 0] *= 0.8
+        h = L.Handle(model, nth, n, seg=seg, seed=9, flags=flags | L.FLAG_ANCESTORS)
+        assert h.nseg > (seg // 2 if seg <= 1024 else 512)        # more segments than threads
+        h.set_params(raws)
+        z0 = h.log_likelihood(y)                                      # no traces: emission from the totals
+        x0, w0, a0 = h.state()
+        z1, lm, es = h.log_likelihood(y, trace=True)                  # full emission at every step
+        assert same(z0, z1)
+        for th in range(nth):
+            f = ob.Filter(model, raws[th], n, seg=seg, seed=9, stream=th, systematic=bool(flags & L.FLAG_SYSTEMATIC))
+            z, olm, oes = f.log_likelihood(y, trace=True)
+            ox, ow, oa, _ = f.state()
+            assert bits([z0[th]])[0] == bits([z])[0] and same(lm[:, th], olm) and same(es[:, th], oes), (model, n, seg)
+            assert same(x0[:, th], ox) and same(w0[th], ow) and np.array_equal(a0[th], oa), (model, n, seg)
+        h.close()
+    # the step API: init, steps, a permutation of the filter slots, more steps
+    n, seg = 50000, 256
+    _, y = ob.simulate(1, LG, 8, 4)
+    h = L.Handle(1, 2, n, seg=seg, seed=21)
+    h.set_params(np.tile(LG, (2, 1)))
+    fs = [ob.Filter(1, LG, n, seg=seg, seed=21, stream=th) for th in range(2)]
+    assert same(h.init(float(y[0])), [f.bootstrap_filter(float(y[0])) for f in fs])
+    for t in range(1, 8):
+        if t == 4:
+            h.permute(np.array([1, 1], dtype=np.int32))     # slot 0 becomes a value copy of slot 1 (keeps its own stream)
+            fs[0].copy_state_from(fs[1])
+        lm, es = h.step(float(y[t]))
+        ref = [f.step(float(y[t])) for f in fs]
+        assert same(lm, [r[0] for r in ref]) and same(es, [r[1] for r in ref]), t
+    x, w, _ = h.state(want_anc=False)
+    for th in range(2):
+        ox, ow, _, _ = fs[th].state()
+        assert same(x[:, th], ox) and same(w[th], ow)
+    h.close()
+
+
+def test_large_filters_beyond_2_pow_20(L):
+    """Nx = 2^22 (2048 segments of 2048: the global segment table) - properties that do not depend on the size: the Kalman pin,
+    determinism, normalised weights, ancestors in range."""
+    from oracle import kalman
+    n, T = 1 << 22, 40
+    _, y = L.simulate(1, LG, T, 1998)
+    kf = kalman.log_likelihood(y, *LG[:4], x0=LG[4], sigma0=LG[5], predict_first=False)[2]
+    h = L.Handle(1, 1, n, seed=3, flags=L.FLAG_ANCESTORS)
+    assert h.seg == 2048 and h.nseg == 2048
+    h.set_params(LG)
+    z = h.log_likelihood(y)
+    x, w, a = h.state()
+    z2 = h.log_likelihood(y)
+    assert bits(z)[0] == bits(z2)[0]
+    assert abs(z[0] - kf) < 8 * np.sqrt(T / n) + 1e-3
+    assert abs(w[0].sum() - 1) < 1e-9 and a[0].min() >= 0 and a[0].max() < n
+    h.close()
+
+
 # ---- opt-in systematic resampling (SMC_FLAG_SYSTEMATIC) ------------------------------------------
 def test_systematic_targets_on_device_are_exact(L):
     rng = np.random.default_rng(11)

@@ -60,9 +60,10 @@ def test_simulate_equals_oracle(L, ob, model, raw):
 
 
 def test_auto_seg_equals_oracle(L, ob):
-    for n in (1, 2, 255, 256, 257, 1000, 1024, 1025, 8192, 8193, 1 << 20, 1 << 21, (1 << 21) + 1, 1 << 24, (1 << 24) + 1, 1 << 25):
+    for n in (1, 2, 255, 256, 257, 1000, 1024, 1025, 8192, 8193, 1 << 20, 1 << 21, (1 << 21) + 1, 1 << 24, (1 << 24) + 1, 1 << 25, (1 << 25) + 1,
+              1 << 26, (1 << 26) + 1, 1 << 27):
         assert L.lib().smc_auto_seg(n) == ob.lib().orc_auto_seg(n)
-        assert (n + L.lib().smc_auto_seg(n) - 1) // L.lib().smc_auto_seg(n) <= 4096     # smc_create's segment limit
+        assert (n + L.lib().smc_auto_seg(n) - 1) // L.lib().smc_auto_seg(n) <= 16384     # smc_create's segment limit
 
 
 def test_systematic_targets_are_exact(L):
