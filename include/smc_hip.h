@@ -267,7 +267,8 @@ int smc_get_quantiles(smc_handle h, int component, const double* p, int np, doub
 int smc_simulate(int model_id, const double* raw, int64_t T, uint64_t seed, double* x /*[d][T]*/, double* y /*[T]*/);
 int smc_model_dim(int model_id);
 int smc_model_nraw(int model_id);
-int smc_auto_seg(int64_t n_x);
+/* the segment length smc_create picks for seg = 0: a function of the model family (its state dimension) and n_x alone */
+int smc_auto_seg(int model_id, int64_t n_x);
 int smc_device_count(void);
 /* the spec's elementary functions on the host (parity tests of the host build) */
 double smc_host_exp(double x);

@@ -46,7 +46,7 @@ def lib():
         L.orc_simulate.argtypes = [C.c_int, _dp, C.c_int, C.c_uint64, _dp, _dp]
         L.orc_normalize.argtypes = [_dp, C.c_int64, _dp, _dp, _dp]
         L.orc_resample.argtypes = [_dp, C.c_int64, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, _i64p]
-        L.orc_auto_seg.argtypes = [C.c_int64]
+        L.orc_auto_seg.argtypes = [C.c_int, C.c_int64]
         L.orc_filter_create.restype = C.c_void_p
         L.orc_filter_create.argtypes = [C.c_int, _dp, C.c_int64, C.c_int, C.c_uint64, C.c_uint32]
         L.orc_filter_destroy.argtypes = [C.c_void_p]

@@ -661,13 +661,15 @@ typedef struct {
 
 void orc_filter_set_systematic(orc_filter* f, int on) { f->systematic = on ? 1 : 0; }
 
-int orc_auto_seg(int64_t n) {   /* the same rule as smc_auto_seg (the segment length is part of the spec) */
+int orc_auto_seg(int model, int64_t n) {   /* the same rule as smc_auto_seg (the segment length is part of the spec) */
+    const int d3 = model == ORC_UCSV3D;
     if (n > (int64_t)16384 * 4096) return 8192;   /* at most 16384 segments */
     if (n > (int64_t)16384 * 2048) return 4096;
-    if (n > ((int64_t)1 << 19)) return 2048;
+    if (n > (int64_t)16384 * 1024) return 2048;
+    if (n > ((int64_t)1 << 19)) return d3 ? 1024 : 2048;
     if (n > ((int64_t)1 << 17)) return 1024;
     if (n > ((int64_t)1 << 15)) return 512;
-    if (n > MAX_SEG) return 256;
+    if (n > (d3 ? 4096 : MAX_SEG)) return 256;
     int s = 256;
     while (s < n) s <<= 1;
     return s;
@@ -675,7 +677,7 @@ int orc_auto_seg(int64_t n) {   /* the same rule as smc_auto_seg (the segment le
 
 orc_filter* orc_filter_create(int model, const double* raw, int64_t n, int seg, uint64_t seed, uint32_t stream) {
     if (n <= 0) return NULL;
-    if (seg == 0) seg = orc_auto_seg(n);
+    if (seg == 0) seg = orc_auto_seg(model, n);
     if (seg < 2 || seg > MAX_SEG || (seg & (seg - 1))) return NULL;
     orc_filter* f = (orc_filter*)calloc(1, sizeof *f);
     if (model_init(&f->model, model, raw)) { free(f); return NULL; }

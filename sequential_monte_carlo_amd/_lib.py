@@ -109,7 +109,7 @@ def lib():
     L.smc_simulate.argtypes = [C.c_int, _dp, C.c_int64, C.c_uint64, _dp, _dp]
     L.smc_model_dim.argtypes = [C.c_int]
     L.smc_model_nraw.argtypes = [C.c_int]
-    L.smc_auto_seg.argtypes = [C.c_int64]
+    L.smc_auto_seg.argtypes = [C.c_int, C.c_int64]
     L.smc_host_exp.restype = C.c_double
     L.smc_host_exp.argtypes = [C.c_double]
     L.smc_host_log.restype = C.c_double

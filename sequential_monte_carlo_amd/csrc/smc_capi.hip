@@ -117,21 +117,26 @@ bool geo_default(int seg, Geo& g) {
 
 // most segments a filter may have (the break points of a step sit in the LDS of k_breaks: 8 B per segment)
 constexpr int MAX_NSEG = 16384;
-extern "C" int smc_auto_seg(int64_t n) {
-    // measured (scripts/nx_sweep.py, scripts/dbg/mid_sizes.py): one segment up to 8192 particles (the batched callers' shape, LDS-
-    // resident); above, the SHORTEST segment whose workgroup still has a thread per segment (nseg <= seg / 2 resp. 512: the
-    // one-record-per-thread window prologue) - a filter of 2^14..2^18 particles is a handful of workgroups on a 256-CU chip and
-    // bound by the life of ONE of them, which shorter segments (fewer particles per workgroup) cut from 9.4 to 6.0-7.3 us per
-    // step; 2048 (512 threads x two pairs: the fastest geometry, 12.5 us per 2^20 particles) from 2^19 particles on for as long
-    // as the segment count allows (2^25 particles) - beyond 512 segments the table of the segments is built once per step by
-    // k_table instead of by every workgroup; 4096 / 8192 keep the count at MAX_NSEG up to 2^26 / 2^27 particles.  The segment
-    // length is part of the numerical spec (the CPU restatement used by the tests follows the same rule).
+extern "C" int smc_auto_seg(int model_id, int64_t n) {
+    // measured (scripts/nx_sweep.py, scripts/dbg/mid_sizes.py, scripts/dbg/ucsv_seg_sweep.py): one segment for as long as the LDS-
+    // resident kernels hold the filter (8192 particles of one state coordinate, 4096 of three: the batched callers' shape);
+    // above, the SHORTEST segment whose workgroup still has a thread per segment (nseg <= seg / 2 resp. 512: the one-record-per-
+    // thread window prologue) - a filter of 2^14..2^18 particles is a handful of workgroups on a 256-CU chip and bound by the
+    // life of ONE of them, which shorter segments (fewer particles per workgroup) cut from 9.4 to 6.0-7.3 us per step; then the
+    // fastest geometry for as long as the segment count allows - one state coordinate: 2048 (512 threads x two pairs, 12.5 us per
+    // 2^20 particles) from 2^19 particles on; three coordinates: 1024 (512 threads x ONE pair: with two pairs the step kernel
+    // needs 183 vector registers and a CU holds one workgroup instead of two - 2^20 UCSV particles 2.9 -> 3.4e10 p-steps/s);
+    // beyond 512 segments the table of the segments is built once per step by k_table instead of by every workgroup; longer
+    // segments keep the count at MAX_NSEG for still larger filters.  The segment length is part of the numerical spec (the CPU
+    // restatement used by the tests follows the same rule).
+    const bool d3 = model_dim_rt(model_id) == 3;
     if (n > (int64_t)MAX_NSEG * 4096) return 8192;
     if (n > (int64_t)MAX_NSEG * 2048) return 4096;
-    if (n > ((int64_t)1 << 19)) return 2048;
+    if (n > (int64_t)MAX_NSEG * 1024) return 2048;
+    if (n > ((int64_t)1 << 19)) return d3 ? 1024 : 2048;
     if (n > ((int64_t)1 << 17)) return 1024;
     if (n > ((int64_t)1 << 15)) return 512;
-    if (n > MAX_SEG) return 256;
+    if (n > (d3 ? 4096 : MAX_SEG)) return 256;
     int s = 256;
     while (s < n) s <<= 1;
     return s;
@@ -259,7 +264,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     if (d < 0) return fail(SMC_EINVAL, "smc_create: unknown model_id " + std::to_string(model_id));
     if (n_theta <= 0 || n_x <= 0) return fail(SMC_EINVAL, "smc_create: n_theta and n_x must be positive");
     if (n_theta > 65535) return fail(SMC_EINVAL, "smc_create: n_theta > 65535 (grid.y limit); shard theta");
-    if (seg == 0) seg = smc_auto_seg(n_x);
+    if (seg == 0) seg = smc_auto_seg(model_id, n_x);
     Geo g;
     if (!geo_default(seg, g)) return fail(SMC_EINVAL, "smc_create: seg must be a power of two in [256,8192]");
 #ifdef SMC_ABLATE

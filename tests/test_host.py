@@ -60,10 +60,11 @@ def test_simulate_equals_oracle(L, ob, model, raw):
 
 
 def test_auto_seg_equals_oracle(L, ob):
-    for n in (1, 2, 255, 256, 257, 1000, 1024, 1025, 8192, 8193, 1 << 20, 1 << 21, (1 << 21) + 1, 1 << 24, (1 << 24) + 1, 1 << 25, (1 << 25) + 1,
+    for n in (1, 2, 255, 256, 257, 1000, 1024, 1025, 8192, 8193, 4096, 4097, 1 << 19, (1 << 19) + 1, 1 << 20, 1 << 21, (1 << 21) + 1, 1 << 24, (1 << 24) + 1, 1 << 25, (1 << 25) + 1,
               1 << 26, (1 << 26) + 1, 1 << 27):
-        assert L.lib().smc_auto_seg(n) == ob.lib().orc_auto_seg(n)
-        assert (n + L.lib().smc_auto_seg(n) - 1) // L.lib().smc_auto_seg(n) <= 16384     # smc_create's segment limit
+        for model in (1, 2, 3):
+            assert L.lib().smc_auto_seg(model, n) == ob.lib().orc_auto_seg(model, n)
+            assert (n + L.lib().smc_auto_seg(model, n) - 1) // L.lib().smc_auto_seg(model, n) <= 16384     # smc_create's segment limit
 
 
 def test_systematic_targets_are_exact(L):
