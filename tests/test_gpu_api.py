@@ -110,21 +110,38 @@ def ucsv_prior():
 UCSV_TMAP = smc.ThetaMap(3, [0, 0, 1, 2, 3], [0.0] * 5)
 
 
-def _run_ucsv(backend, online=False, device=False):
+def _run_ucsv(backend, online=False, device=False, N=256, M=24, T=20):
     u = smc.UCSV((0.2, 0.2), 3.0, (0.0, 0.0))
-    _, y = smc.simulate(u, 20, seed=1998)
-    s = smc.SMC(256, 24, ucsv_mod, ucsv_prior(), 2, 0.7 if online else 0.5, seed=3, backend=backend,
+    _, y = smc.simulate(u, T, seed=1998)
+    s = smc.SMC(N, M, ucsv_mod, ucsv_prior(), 2, 0.7 if online else 0.5, seed=3, backend=backend,
                 theta_map=UCSV_TMAP if device else None)
     assert s.device_pmmh == device
     buf = io.StringIO()
     if online:
         smc.smc2(s, y)
-        for t in range(2, 21):
+        for t in range(2, T + 1):
             smc.smc2_step(s, y, t, verbose=True, out=buf)
         x, w, _ = s._main.state()
         return s, buf.getvalue(), x, w
     stages = smc.density_tempered(s, y, verbose=True, out=buf)
     return s, buf.getvalue(), stages, None
+
+
+def test_samplers_over_multi_segment_inner_filters():
+    """examples/inflation_example.jl:256 runs SMC(8192, 512, ...) on UCSV: inner filters of more state particles than the LDS-
+    resident kernel holds run as several segments (UCSV: above 4096 particles), one launch per step, the PMMH proposal filters and
+    the online propagation included.  density_tempered and the online sampler with 4608 state particles (18 segments of 256), device
+    rejuvenation, against the oracle backend - bit for bit."""
+    sh, th, stg_h, _ = _run_ucsv(smc.smc_samplers.HipBackend(), device=True, N=4608, M=8, T=10)
+    so, to, stg_o, _ = _run_ucsv(OracleBackend(), device=True, N=4608, M=8, T=10)
+    assert sh._main is None or not sh._main.resident
+    assert th == to and stg_h == stg_o
+    assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ)) and sh.psteps == so.psteps
+    sh, th, xh, wh = _run_ucsv(smc.smc_samplers.HipBackend(), online=True, device=True, N=4608, M=8, T=10)
+    so, to, xo, wo = _run_ucsv(OracleBackend(), online=True, device=True, N=4608, M=8, T=10)
+    assert sh._main.nseg == 18 and th == to
+    assert np.array_equal(bits(sh.theta), bits(so.theta)) and np.array_equal(bits(sh.logZ), bits(so.logZ))
+    assert np.array_equal(bits(xh), bits(xo)) and np.array_equal(bits(wh), bits(wo))
 
 
 @pytest.mark.parametrize("device", [False, True])
