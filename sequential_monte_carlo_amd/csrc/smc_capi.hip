@@ -164,7 +164,7 @@ static hipError_t do_init(smc_filter_s* h, double y) {
 // emit as k_step's emit_prev: 0 nothing, 1 (logmu, ess) from the full records, 2 from the totals)
 static hipError_t do_table(smc_filter_s* h, int emit, int first_emit, uint32_t t_emit) {
     constexpr int TH = 1024;
-    hipLaunchKernelGGL((k_table<TH>), dim3(h->v.ntheta), dim3(TH), scr_words(TH, 1) * 8, h->stream, h->v, h->cur, emit, first_emit, t_emit);
+    hipLaunchKernelGGL((k_table<TH>), dim3(h->v.ntheta), dim3(TH), 0, h->stream, h->v, h->cur, emit, first_emit, t_emit);
     return hipGetLastError();
 }
 static hipError_t do_step(smc_filter_s* h, uint32_t t, int emit_prev, double y) {

@@ -1378,16 +1378,85 @@ __global__ __launch_bounds__(THREADS) void k_finalize(FilterView v, int cur, int
 // ---------------------------------------------------------------------------------------------
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_table(FilterView v, int cur, int emit, int first_emit, uint32_t t_emit) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int th = blockIdx.x;
+    constexpr int NW = THREADS / WAVE;
+    constexpr int DEADK = (int)0x80000000;
+    __shared__ int redk[NW];
+    __shared__ uint64_t wt[NW], wr[NW];
+    const int th = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     if (v.skip && v.skip[th]) return;
-    TableLds L;
-    L.Dcum = v.tabD + (size_t)th * v.nseg_p2;
-    L.sh = v.tabsh + (size_t)th * v.nseg_p2;
-    L.scr = (uint64_t*)smem;
-    double K;
-    const uint64_t Dtot = table_prologue<THREADS>(v, cur, th, L, emit == 1, first_emit != 0, t_emit, nullptr, &K);
-    if (emit == 2 && threadIdx.x == 0) emit_from_totals(v, th, K, Dtot, first_emit != 0, t_emit);
+    const size_t base = (size_t)th * v.nseg;
+    const double* sk = v.segk[cur] + base;
+    const uint64_t* sS = v.segS[cur] + base;
+    uint64_t* Dcum = v.tabD + (size_t)th * v.nseg_p2;
+    int* shv = v.tabsh + (size_t)th * v.nseg_p2;
+    // the exponent maximum: a coalesced sweep over the records
+    int ki = DEADK;
+    for (int b = tid; b < v.nseg; b += THREADS) {
+        const double k = sk[b];
+        const int kb = k == -inf() ? DEADK : (int)k;
+        ki = kb > ki ? kb : ki;
+    }
+    ki = wave_max_i32(ki);
+    if (lane == 0) redk[wave] = ki;
+    __syncthreads();
+    int km = redk[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) km = redk[w] > km ? redk[w] : km;
+    const double K = km == DEADK ? -inf() : (double)km;
+    // wave w owns the 64 E consecutive entries from w 64 E on, lane l the entries l, l + 64, ... of them: every load and store of a
+    // wave is one contiguous run of records; E short scans with a carried total; the inclusive sums stay in registers until
+    // the offsets of the waves are known (stores only: nothing of the table is read back)
+    constexpr int EMAX = 16;   // nseg_p2 <= 16384
+    const int E = v.nseg_p2 >= THREADS ? v.nseg_p2 / THREADS : 1, w0 = wave * E * WAVE;
+    uint64_t inc[EMAX], carry = 0, rsum = 0;
+    int she[EMAX];
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        inc[i] = 0; she[i] = 64;
+        if (i < E) {   // wave-uniform
+            const int b = w0 + i * WAVE + lane;
+            uint64_t Q = 0;
+            if (b < v.nseg) {
+                she[i] = seg_shift(K, sk[b], v.SH);
+                Q = seg_Q(sS[b], she[i]);
+                if (emit == 1) rsum += seg_R(v.segS2hi[cur][base + b], v.segS2lo[cur][base + b], she[i], v.SH);
+            }
+            inc[i] = wave_incl_scan(Q, lane) + carry;
+            carry = readlane_u64(inc[i], WAVE - 1);
+        }
+    }
+    if (lane == 0) wt[wave] = carry;
+    if (emit == 1) {
+        const uint64_t rw = wave_sum(rsum);
+        if (lane == 0) wr[wave] = rw;
+    }
+    __syncthreads();
+    uint64_t off = 0, Dtot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { off += w < wave ? wt[w] : 0; Dtot += wt[w]; }
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i)
+        if (i < E) {
+            const int b = w0 + i * WAVE + lane;
+            if (b < v.nseg_p2) { Dcum[b] = off + inc[i]; shv[b] = she[i]; }
+        }
+    if (emit == 1 && tid == 0) {   // (logmu, ess) of these weights: what table_prologue's emitting thread does
+        uint64_t Rtot = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) Rtot += wr[w];
+        double logmu, ess;
+        combine_outputs(K, Dtot, Rtot, v.SH, v.n, logmu, ess);
+        v.last_logmu[th] = logmu;
+        v.last_ess[th] = ess;
+        v.last_K[th] = K;
+        v.last_D[th] = Dtot;
+        if (v.trace_logmu) v.trace_logmu[(size_t)t_emit * v.ntheta + th] = logmu;
+        if (v.trace_ess) v.trace_ess[(size_t)t_emit * v.ntheta + th] = ess;
+        const double z = first_emit ? logmu : v.logZ[th] + logmu;
+        v.logZ[th] = z;
+        host_emit(v, th, z, logmu, ess);
+    }
+    if (emit == 2 && tid == 0) emit_from_totals(v, th, K, Dtot, first_emit != 0, t_emit);
 }
 
 }  // namespace smc
