@@ -47,9 +47,9 @@ typedef struct smc_filter_s* smc_handle;
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* n_theta independent bootstrap filters of n_x particles each (the batched callers
  * src/smc_samplers.jl:112-121,223-229,289-295,325-335 become ONE handle with n_theta > 1).
- * seg: particles per segment (power of two in [256,8192]); 0 = automatic. It is part of the
- * random-number contract like the seed.  Filter m uses Philox stream id m until
- * smc_set_streams says otherwise. */
+ * seg: particles per segment (power of two in [256,8192]); 0 = automatic (smc_auto_seg). It is part of the
+ * random-number contract like the seed.  A filter has at most 16384 segments (n_x <= 2^27 with seg = 8192; the automatic
+ * choice keeps segments of 2048 up to 2^25 particles).  Filter m uses Philox stream id m until smc_set_streams says otherwise. */
 int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, uint64_t seed, int device, uint32_t flags,
                smc_handle* out);
 int smc_destroy(smc_handle h);
