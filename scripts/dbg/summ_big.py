@@ -7,7 +7,7 @@ from sequential_monte_carlo_amd import _lib as L
 LGR = [0.5, 1.0, 0.9, 0.8, 0.0, 1.0]
 m = smc.UnivariateLinearGaussian(A=0.5, B=1.0, Q=0.9, R=0.8)
 _, y = smc.simulate(m, 300)
-for n in (2**16, 2**20):
+for n in (2**16, 2**20, 2**22):
     h = L.Handle(1, 1, n, seed=3)
     h.set_params(np.array([LGR]))
     for name, ps, mom in (("none", None, False), ("moments", None, True), ("1 level", [0.5], False), ("3 levels + moments", [0.25, 0.5, 0.75], True)):

@@ -708,8 +708,16 @@ static int enqueue_ms(smc_handle h, int component, int np, const uint64_t* p64, 
     hipLaunchKernelGGL(k_ms_range, dim3(g_read, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, h->d, ms);
     if (np > 0) hipLaunchKernelGGL(k_ms_hist, dim3(g_hist, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, g_read, ms);
     hipLaunchKernelGGL(k_ms_pick, dim3(h->v.ntheta), dim3(MS_THREADS), 0, h->stream, v, h->d, g_read, ms, q_out, mean, var);
+    int64_t two_level = MS_TWO_LEVEL;
+    if (const char* e = getenv("SMC_MS_TWO_LEVEL")) two_level = atoll(e);   // tuning / test knob: results do not depend on it
+    if (np > 0 && h->v.n > two_level) {   // big filters: the chosen bins cut a second time before the candidates are collected
+        hipLaunchKernelGGL(k_ms_hist2, dim3(g_read, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, ms);
+        hipLaunchKernelGGL(k_ms_pick2, dim3(np, h->v.ntheta), dim3(MS_THREADS), 0, h->stream, v, ms);
+        hipLaunchKernelGGL(k_ms_collect<true>, dim3(g_read, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, ms);
+    } else if (np > 0) {
+        hipLaunchKernelGGL(k_ms_collect<false>, dim3(g_read, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, ms);
+    }
     if (np > 0) {
-        hipLaunchKernelGGL(k_ms_collect, dim3(g_read, h->v.ntheta), dim3(MS_STREAM), 0, h->stream, v, h->cur, ms);
         hipLaunchKernelGGL(k_ms_select, dim3(np, h->v.ntheta), dim3(MS_SEL_THREADS), 0, h->stream, v, h->cur, ms, q_out);
     }
     HIPCHK(hipGetLastError());

@@ -26,6 +26,7 @@ namespace smc {
 
 constexpr int MS_BINS = 4096, MS_CAP = 3072, MS_THREADS = 256, MS_SEL_THREADS = 512;   // (MS_CAP: 48 KB of candidates in LDS)
 constexpr int MS_STREAM = 1024;   // threads of the kernels that stream over the particles (k_ms_range, k_ms_hist, k_ms_collect)
+constexpr int64_t MS_TWO_LEVEL = (int64_t)1 << 21;   // filters of more particles cut the chosen bin a second time (4096 x 4096 value bins)
 constexpr int MS_STASH = 64;      // matches a workgroup of k_ms_collect keeps in LDS per level before it asks for room in the list
 
 // scratch of one handle, in 8-byte words (zeroed once when allocated; the kernels leave hist and cnt zeroed again)
@@ -35,12 +36,13 @@ struct MsScratch {
     double* mpart;               // [ntheta][d][parts][2]  partial sums of w x, w x^2
     unsigned long long* hist;    // [ntheta][MS_BINS]
     uint64_t* hdr;               // [ntheta][4]            lo, scale (doubles) | usable (0 / 1) | total weight
-    uint64_t* st;                // [ntheta][QMAX][4]      bin | weight below | target | state (0 fallback, 1 binned, 2 no weight)
+    uint64_t* st;                // [ntheta][QMAX][6]      bin | weight below | target | state (0 fallback, 1 binned, 2 no weight) | sub-bin | -
+    unsigned long long* hist2;   // [ntheta][QMAX][MS_BINS]  second level (filters beyond MS_TWO_LEVEL particles): the chosen bin cut again
     unsigned* cnt;               // [ntheta][QMAX]         candidates collected per level
     uint64_t* cand;              // [ntheta][QMAX][MS_CAP][2]   (key, W)
 };
 __host__ __device__ inline size_t ms_words(size_t nth, size_t nseg, size_t d) {
-    return nth * nseg * 2 + nth * d * nseg * 2 + nth * MS_BINS + nth * 4 + nth * QMAX * 4 + nth * QMAX + nth * QMAX * MS_CAP * 2;
+    return nth * nseg * 2 + nth * d * nseg * 2 + nth * MS_BINS + nth * 4 + nth * QMAX * 6 + nth * QMAX * MS_BINS + nth * QMAX + nth * QMAX * MS_CAP * 2;
 }
 __host__ __device__ inline MsScratch ms_carve(uint64_t* base, size_t nth, size_t nseg, size_t d) {
     MsScratch s;
@@ -48,7 +50,8 @@ __host__ __device__ inline MsScratch ms_carve(uint64_t* base, size_t nth, size_t
     s.mpart = (double*)base; base += nth * d * nseg * 2;
     s.hist = (unsigned long long*)base; base += nth * MS_BINS;
     s.hdr = base; base += nth * 4;
-    s.st = base; base += nth * QMAX * 4;
+    s.st = base; base += nth * QMAX * 6;
+    s.hist2 = (unsigned long long*)base; base += nth * QMAX * MS_BINS;
     s.cnt = (unsigned*)base; base += nth * QMAX;
     s.cand = base;
     return s;
@@ -66,6 +69,15 @@ __device__ __forceinline__ MsSeg ms_segment(const FilterView& v, int cur, int th
 __device__ __forceinline__ int ms_bin(double x, double lo, double scale) {
     const int b = (int)((x - lo) * scale);   // monotone in x: differences, products and truncation all are
     return b < MS_BINS - 1 ? b : MS_BINS - 1;
+}
+// ... and the position inside that bin, cut into MS_BINS again (monotone in x among the values of one bin)
+__device__ __forceinline__ int ms_bin2(double x, double lo, double scale, int& sub) {
+    const double f = (x - lo) * scale;
+    int b = (int)f;
+    b = b < MS_BINS - 1 ? b : MS_BINS - 1;
+    const int s2 = (int)((f - (double)b) * (double)MS_BINS);
+    sub = s2 < MS_BINS - 1 ? s2 : MS_BINS - 1;
+    return b;
 }
 
 // The particles of the segments this workgroup owns (grid.x workgroups share the nseg segments of filter th, consecutive segments
@@ -223,9 +235,9 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_pick(FilterView v, int d, int
         }
     const int nq = v.sum_np;
     if (nq == 0) return;
-    uint64_t* st = ms.st + (size_t)th * QMAX * 4;
+    uint64_t* st = ms.st + (size_t)th * QMAX * 6;
     if (!ms.hdr[(size_t)th * 4 + 2]) {   // no usable range: the select kernel streams over the whole filter
-        if (tid < nq) st[tid * 4 + 3] = 0;
+        if (tid < nq) st[tid * 6 + 3] = 0;
         return;
     }
     unsigned long long* hb = ms.hist + (size_t)th * MS_BINS + (size_t)tid * PER;
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_pick(FilterView v, int d, int
     if (tid == 0) ms.hdr[(size_t)th * 4 + 3] = tot;
     for (int j = 0; j < nq; ++j) {
         if (!tot) {   // every weight is zero: no quantile
-            if (tid == 0) { st[j * 4 + 3] = 2; q_out[(size_t)th * nq + j] = bits2d(0x7ff8000000000000ULL); }
+            if (tid == 0) { st[j * 6 + 3] = 2; q_out[(size_t)th * nq + j] = bits2d(0x7ff8000000000000ULL); }
             continue;
         }
         const uint64_t target = __umul64hi(v.sum_p64[j], tot);
@@ -251,10 +263,10 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_pick(FilterView v, int d, int
 #pragma unroll
             for (int t = 0; t < PER; ++t) {
                 if (h[t] && run <= target && target < run + h[t]) {
-                    st[j * 4] = (uint64_t)(tid * PER + t);
-                    st[j * 4 + 1] = run;
-                    st[j * 4 + 2] = target;
-                    st[j * 4 + 3] = 1;
+                    st[j * 6] = (uint64_t)(tid * PER + t);
+                    st[j * 6 + 1] = run;
+                    st[j * 6 + 2] = target;
+                    st[j * 6 + 3] = 1;
                 }
                 run += h[t];
             }
@@ -262,8 +274,57 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_pick(FilterView v, int d, int
     }
 }
 
+// second level (filters beyond MS_TWO_LEVEL particles): the particles of every level's chosen bin, a few thousand, cut into MS_BINS
+// sub-bins - few enough for device-scope atomics straight into the level's histogram.  grid (G, ntheta)
+__global__ __launch_bounds__(MS_STREAM) void k_ms_hist2(FilterView v, int cur, MsScratch ms) {
+    const int th = blockIdx.y, nq = v.sum_np;
+    if (!ms.hdr[(size_t)th * 4 + 2] || !ms.hdr[(size_t)th * 4 + 3]) return;
+    const double lo = bits2d(ms.hdr[(size_t)th * 4]), scale = bits2d(ms.hdr[(size_t)th * 4 + 1]);
+    int sb[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) sb[j] = j < nq ? (int)ms.st[((size_t)th * QMAX + j) * 6] : -1;
+    ms_for_each(v, cur, th, v.sum_comp, [&](int64_t, uint64_t q, double x, const MsSeg& sg) {
+        const uint64_t W = sg.sh < 64 ? q >> sg.sh : 0;
+        if (!W) return;
+        int sub;
+        const int bin = ms_bin2(x, lo, scale, sub);
+#pragma unroll
+        for (int l = 0; l < QMAX; ++l)
+            if (bin == sb[l]) atomicAdd(&ms.hist2[((size_t)th * QMAX + l) * MS_BINS + sub], (unsigned long long)W);
+    });
+}
+// grid (nq, ntheta): the sub-bin the level's target falls in, and the weight below it
+__global__ __launch_bounds__(MS_THREADS) void k_ms_pick2(FilterView v, MsScratch ms) {
+    constexpr int NW = MS_THREADS / WAVE, PER = MS_BINS / MS_THREADS;
+    __shared__ uint64_t wt[NW];
+    const int jq = blockIdx.x, th = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    uint64_t* st = ms.st + ((size_t)th * QMAX + jq) * 6;
+    if (!ms.hdr[(size_t)th * 4 + 2] || st[3] != 1) return;   // no usable range / no weight: nothing was binned
+    unsigned long long* hb = ms.hist2 + ((size_t)th * QMAX + jq) * MS_BINS + (size_t)tid * PER;
+    uint64_t h[PER], sum = 0;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { h[t] = hb[t]; hb[t] = 0; sum += h[t]; }   // (zeroed for the next use)
+    const uint64_t incl_w = wave_incl_scan(sum, lane);
+    if (lane == WAVE - 1) wt[wave] = incl_w;
+    const uint64_t below = st[1], target = st[2];
+    __syncthreads();
+    uint64_t off = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) off += w < wave ? wt[w] : 0;
+    const uint64_t excl = below + off + incl_w - sum;
+    if (sum && excl <= target && target < excl + sum) {   // exactly one thread (the bin's weight holds the target)
+        uint64_t run = excl;
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            if (h[t] && run <= target && target < run + h[t]) { st[4] = (uint64_t)(tid * PER + t); st[1] = run; }
+            run += h[t];
+        }
+    }
+}
+
 // grid (G, ntheta): a workgroup keeps its matches in LDS (MS_STASH per level) and asks for room in the level's list ONCE - the
 // list's counter is one address all workgroups of a filter share; a match beyond the stash asks by itself
+template <bool TWO>
 __global__ __launch_bounds__(MS_STREAM) void k_ms_collect(FilterView v, int cur, MsScratch ms) {
     __shared__ uint64_t stash[QMAX][MS_STASH][2];
     __shared__ unsigned ln[QMAX], lbase[QMAX];
@@ -272,16 +333,20 @@ __global__ __launch_bounds__(MS_STREAM) void k_ms_collect(FilterView v, int cur,
     const double lo = bits2d(ms.hdr[(size_t)th * 4]), scale = bits2d(ms.hdr[(size_t)th * 4 + 1]);
     int sb[QMAX];
 #pragma unroll
-    for (int j = 0; j < QMAX; ++j) sb[j] = j < nq ? (int)ms.st[((size_t)th * QMAX + j) * 4] : -1;
+    for (int j = 0; j < QMAX; ++j) sb[j] = j < nq ? (int)ms.st[((size_t)th * QMAX + j) * 6] : -1;
+    int ssub[QMAX];
+#pragma unroll
+    for (int j = 0; j < QMAX; ++j) ssub[j] = (TWO && j < nq) ? (int)ms.st[((size_t)th * QMAX + j) * 6 + 4] : 0;
     if (tid < QMAX) ln[tid] = 0;
     __syncthreads();
     ms_for_each(v, cur, th, v.sum_comp, [&](int64_t, uint64_t q, double x, const MsSeg& sg) {
         const uint64_t W = sg.sh < 64 ? q >> sg.sh : 0;
         if (!W) return;
-        const int bin = ms_bin(x, lo, scale);
+        int sub = 0;
+        const int bin = TWO ? ms_bin2(x, lo, scale, sub) : ms_bin(x, lo, scale);
 #pragma unroll
         for (int l = 0; l < QMAX; ++l)
-            if (bin == sb[l]) {
+            if (bin == sb[l] && (!TWO || sub == ssub[l])) {
                 const unsigned k = atomicAdd(&ln[l], 1u);
                 if (k < (unsigned)MS_STASH) {
                     stash[l][k][0] = order_key(x);
@@ -320,7 +385,7 @@ __global__ __launch_bounds__(MS_SEL_THREADS) void k_ms_select(FilterView v, int 
     __shared__ uint64_t wt[NW], ck_mx[NW];
     __shared__ uint64_t sel[2];   // prefix, below
     const int jq = blockIdx.x, th = blockIdx.y, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE, nq = v.sum_np;
-    const uint64_t* st = ms.st + ((size_t)th * QMAX + jq) * 4;
+    const uint64_t* st = ms.st + ((size_t)th * QMAX + jq) * 6;
     const uint64_t state = st[3];
     const unsigned c = ms.cnt[(size_t)th * QMAX + jq];
     __syncthreads();

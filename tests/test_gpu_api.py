@@ -524,8 +524,12 @@ def test_per_step_summaries_inside_the_multi_step_calls(ob):
              # several segments (csrc/smc_summ_kernels.h) and its fallbacks: clusters of equal values overflow a bin's candidate
              # list, a cloud of ONE value has no range (both: the radix select streams over the whole filter); 2^17 particles
              (1, LGZ, 9000, 1024, 1, 0, 0), (1, LGC, 9000, 2048, 2, 0, 0), (1, LGR, 2**17, 0, 1, 0, 0),
-             (1, LGE, 1024, 0, 1, 0, 0), (1, LGE, 5000, 1024, 1, 0, 0))
-    for model, raw, n, seg, nth, comp, flags in cases:
+             (1, LGE, 1024, 0, 1, 0, 0), (1, LGE, 5000, 1024, 1, 0, 0),
+             (1, LGR, 40000, 256, 1, 0, 0))   # more segments than threads: the segment table from k_table
+    for model, raw, n, seg, nth, comp, flags in cases + (("two-level", UCR, 6000, 512, 2, 0, 0), ("two-level", LGC, 9000, 1024, 1, 0, 0)):
+        if model == "two-level":   # filters beyond 2^21 particles cut the chosen value bin a second time: the same path at small sizes
+            os.environ["SMC_MS_TWO_LEVEL"] = "1000"
+            model = 3 if raw is UCR else 1
         T = 12
         _, y = ob.simulate(model, LGR if model == 1 else raw, T, 5)
         ps = ps_all if n < 8192 else ps_all[1:5]   # (the histograms of seven levels do not fit next to 8192 particles in LDS: that call
@@ -578,6 +582,7 @@ def test_per_step_summaries_inside_the_multi_step_calls(ob):
             lm_next, _ = h.step(float(y[7]))
             assert np.array_equal(bits(lm_next), bits(lm0[7]))
         h.close()
+    os.environ.pop("SMC_MS_TWO_LEVEL", None)
     # collapsed filter: NaN quantiles at every step, the call still returns
     h = L.Handle(2, 1, 512, seed=1)
     h.set_params(SVR)
