@@ -1337,13 +1337,37 @@ static int fix_bits_for(int64_t n) {
     return k > FIX_BITS ? FIX_BITS : k;
 }
 
-// Scratch of the stand-alone entry points: device buffers that are released on every way out of the function, and a
-// private non-blocking stream per (host thread, device) so that these calls never serialise against the null stream.
+// Scratch of the stand-alone entry points: device buffers kept per (host thread, slot) and grown on demand - hipMalloc / hipFree of a
+// whole cloud's worth on every call cost 30 ms per normalize at 2^20 entries, ten times the work - released when the thread
+// ends; and a private non-blocking stream per (host thread, device) so that these calls never serialise against the null stream.
 namespace {
-struct DevBuf {
+struct ScratchSlot {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    size_t cap = 0;
+    int device = -1;
+    ~ScratchSlot() { if (p) (void)hipFree(p); }
+};
+struct DevBuf {   // a view of one cached slot: alloc() may be called once per call and slot
+    void* p = nullptr;
+    int slot;
+    explicit DevBuf(int s) : slot(s) {}
+    hipError_t alloc(size_t bytes) {
+        static thread_local ScratchSlot slots[8];
+        ScratchSlot& c = slots[slot];
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        bytes = bytes ? bytes : 16;
+        if (c.cap < bytes || c.device != dev) {
+            if (c.p) { (void)hipFree(c.p); c.p = nullptr; c.cap = 0; }
+            e = hipMalloc(&c.p, bytes);
+            if (e != hipSuccess) return e;
+            c.cap = bytes;
+            c.device = dev;
+        }
+        p = c.p;
+        return hipSuccess;
+    }
     template <class T> T* as() const { return (T*)p; }
 };
 hipError_t util_stream(int device, hipStream_t* out) {
@@ -1364,7 +1388,7 @@ extern "C" int smc_normalize(const double* logw, int64_t n, double* w, double* l
     if (!logw || !w || n <= 0) return fail(SMC_EINVAL, "smc_normalize: bad argument");
     hipStream_t st = nullptr;
     HIPCHK(util_stream(device, &st));
-    DevBuf d_in, d_w, d_o;
+    DevBuf d_in(0), d_w(1), d_o(2);
     HIPCHK(d_in.alloc((size_t)n * 8));
     HIPCHK(d_w.alloc((size_t)n * 8));
     HIPCHK(d_o.alloc(16));
@@ -1375,7 +1399,7 @@ extern "C" int smc_normalize(const double* logw, int64_t n, double* w, double* l
         HIPCHK(hipGetLastError());
     } else {
         // a whole cloud's log-weights: three grid-wide passes, every cross-workgroup combination an integer one (same bits)
-        DevBuf d_acc;
+        DevBuf d_acc(3);
         HIPCHK(d_acc.alloc(5 * 8));
         unsigned long long* acc = d_acc.as<unsigned long long>();
         int* kmax_i = reinterpret_cast<int*>(acc + 4);
@@ -1413,7 +1437,7 @@ extern "C" int smc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t 
     if (ndraw == 0) return SMC_OK;
     hipStream_t st = nullptr;
     HIPCHK(util_stream(device, &st));
-    DevBuf d_w, d_C, d_a, d_st;
+    DevBuf d_w(0), d_C(1), d_a(2), d_st(3);
     HIPCHK(d_w.alloc((size_t)n * 8));
     HIPCHK(d_C.alloc((size_t)n * 8));
     HIPCHK(d_a.alloc((size_t)ndraw * 4));
@@ -1438,7 +1462,7 @@ extern "C" int smc_kalman_log_likelihood(const double* raw, int64_t n_theta, con
     if (!raw || !y || !out || n_theta <= 0 || T <= 0) return fail(SMC_EINVAL, "smc_kalman_log_likelihood: bad argument");
     hipStream_t st = nullptr;
     HIPCHK(util_stream(device, &st));
-    DevBuf d_raw, d_y, d_out;
+    DevBuf d_raw(0), d_y(1), d_out(2);
     HIPCHK(d_raw.alloc((size_t)n_theta * 48));
     HIPCHK(d_y.alloc((size_t)T * 8));
     HIPCHK(d_out.alloc((size_t)n_theta * 24));
@@ -1608,7 +1632,7 @@ extern "C" int smc_sys_targets(uint64_t Dtot, uint32_t n, uint64_t u, uint64_t j
     }
     hipStream_t st = nullptr;
     HIPCHK(util_stream(device, &st));
-    DevBuf d;
+    DevBuf d(0);
     HIPCHK(d.alloc((size_t)nk * 8));
     hipLaunchKernelGGL(k_sys_targets, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, Dtot, n, u, j0, nk, d.as<uint64_t>());
     HIPCHK(hipGetLastError());
@@ -1622,7 +1646,7 @@ extern "C" int smc_device_math(int which, const double* a, const double* b, int6
     if (which >= 3 && !b) return fail(SMC_EINVAL, "smc_device_math: b required");
     hipStream_t st = nullptr;
     HIPCHK(util_stream(device, &st));
-    DevBuf da, db, dout;
+    DevBuf da(0), db(1), dout(2);
     HIPCHK(da.alloc((size_t)n * 8));
     HIPCHK(db.alloc((size_t)n * 8));
     HIPCHK(dout.alloc((size_t)n * 8));
