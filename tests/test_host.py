@@ -414,3 +414,43 @@ def test_exchange_plan_c_equals_python_and_is_consistent(L):
                     off += len(chunk)
             assert np.array_equal(np.concatenate(new), a)
     assert lib.smc_comm_plan_exchange(None, 4, 0, 2, None, None, None, None, None) == -1
+
+
+def test_julia_binding_blocks_and_brackets_balance():
+    """No Julia in the image: at least the gross structure of julia/hip_backend.jl is checked - every bracket closes, every block
+    opener outside brackets (function, if, for, while, struct, try, ...) has its `end` (comments and string literals skipped)."""
+    import re
+    src = open(os.path.join(ROOT, "julia", "hip_backend.jl"), encoding="utf-8").read()
+    out, i = [], 0
+    while i < len(src):
+        c = src[i]
+        if c == "#":
+            while i < len(src) and src[i] != "\n":
+                i += 1
+            continue
+        if c == '"':
+            i += 1
+            while i < len(src) and src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+            i += 1
+            out.append('""')
+            continue
+        out.append(c)
+        i += 1
+    code = "".join(out)
+    openers = {"function", "if", "for", "while", "struct", "try", "let", "do", "begin", "quote", "module", "macro"}
+    close = {")": "(", "]": "[", "}": "{"}
+    brackets, blocks = [], []
+    for m in re.finditer(r"[A-Za-z_²θξωμ!][A-Za-z_0-9²θξωμ!]*|[()\[\]{}]", code):
+        t, line = m.group(0), code.count("\n", 0, m.start()) + 1
+        if t in "([{":
+            brackets.append((t, line))
+        elif t in ")]}":
+            assert brackets and brackets[-1][0] == close[t], "bracket mismatch at line %d" % line
+            brackets.pop()
+        elif not brackets and t in openers:
+            blocks.append((t, line))
+        elif not brackets and t == "end":
+            assert blocks, "`end` without a block at line %d" % line
+            blocks.pop()
+    assert not brackets and not blocks, (brackets[:3], blocks[:3])
