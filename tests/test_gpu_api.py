@@ -604,6 +604,50 @@ def test_per_step_summaries_inside_the_multi_step_calls(ob):
     assert s["quantiles"].shape == (30, 3) and s["mean"].shape == (30,)
 
 
+def test_per_step_summaries_randomized(ob):
+    """Fuzz of the per-step summaries: random model / parameters / Nx / segment length / batch / levels / coordinate - the quantiles of
+    every step bit-identical to the oracle's sort (LDS-resident selection, its radix fallback, the five- and seven-launch paths of
+    filters of several segments), the moments to rounding."""
+    from sequential_monte_carlo_amd import _lib as L
+    iters = int(os.environ.get("SMC_FUZZ_ITERS", "30"))
+    rng = np.random.default_rng(20261005)
+    SIM = {1: [0.7, 1.0, 1.0, 0.5, 0.0, 1.0], 2: [-1.0, 0.95, 0.25], 3: [0.2, 0.2, 3.0, 0.0, 0.0]}
+    for it in range(iters):
+        model = int(rng.integers(1, 4))
+        seg = int(rng.choice([0, 256, 512, 1024, 2048]))
+        n = int(rng.integers(2, 9000)) if rng.random() < 0.8 else int(rng.integers(9000, 70000))
+        nth = int(rng.integers(1, 3))
+        T = int(rng.integers(2, 6))
+        seed = int(rng.integers(1, 2**62))
+        if model == 1:
+            raw = [rng.uniform(-1, 1), rng.uniform(0.5, 2), rng.lognormal(0, 1) * (rng.random() < 0.85), rng.lognormal(-1, 1.5), rng.normal(0, 2), rng.lognormal(0, 1)]
+        elif model == 2:
+            raw = [rng.normal(-1, 1), rng.uniform(-0.98, 0.98), rng.lognormal(-1, 0.5)]
+        else:
+            raw = [rng.uniform(0.02, 0.8), rng.uniform(0.02, 0.8), rng.normal(3, 2), rng.uniform(-2, 2), rng.uniform(-2, 2)]
+        d = 3 if model == 3 else 1
+        comp = int(rng.integers(0, d))
+        ps = sorted(set([float(p) for p in rng.uniform(0, 1, int(rng.integers(1, 6)))] + ([0.0] if rng.random() < 0.3 else []) + ([1.0] if rng.random() < 0.3 else [])))
+        if rng.random() < 0.25:
+            os.environ["SMC_MS_TWO_LEVEL"] = "500"
+        _, y = ob.simulate(model, SIM[model], T, int(rng.integers(1, 1000)))
+        h = L.Handle(model, nth, n, seg=seg, seed=seed)
+        h.set_params(np.tile(raw, (nth, 1)))
+        h.set_summaries(ps, comp, moments=True)
+        h.log_likelihood(y)
+        q, mean, var = h.get_summaries(T)
+        os.environ.pop("SMC_MS_TWO_LEVEL", None)
+        for th in range(nth):
+            f = ob.Filter(model, raw, n, seg=seg, seed=seed, stream=th)
+            for t in range(T):
+                f.bootstrap_filter(float(y[0])) if t == 0 else f.step(float(y[t]))
+                ctx = (it, model, n, seg, nth, th, t, ps, comp)
+                assert np.array_equal(bits(q[t, th]), bits(f.quantiles(ps, comp))), ctx
+                om, ov = f.moments()
+                assert np.allclose(mean[t, :, th], om, rtol=1e-10, atol=1e-12) and np.allclose(var[t, :, th], ov, rtol=1e-7, atol=1e-11), ctx
+        h.close()
+
+
 GPU_GLOO_WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
