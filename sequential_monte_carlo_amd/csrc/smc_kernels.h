@@ -934,9 +934,13 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         stg1[k] = (!MULTI && EARLY1) ? reinterpret_cast<const ulonglong2*>(Cprev)[tid + k * THREADS] : ulonglong2{0, 0};
 
     // ---- the state normals of this thread's children (under the loads of the records, the break points and the staged segments) ----------------
+    // (three state coordinates, two pairs per thread: twelve normals held across the table, the targets and the search push the
+    //  kernel to 183 vector registers - ONE workgroup per CU; they are computed next to their use instead, below)
+    constexpr bool LATE_Z = D == 3 && NP >= 2 && !SYS;
     double z[NP][D][2];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
+        if (LATE_Z) break;
         const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
 #pragma unroll
         for (int c = 0; c < D; ++c) {
@@ -1231,6 +1235,11 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
     for (int k = 0; k < NP; ++k) {
         const uint32_t i0 = seg0 + 2 * (tid + k * THREADS);
         double xn[2][D];
+        if (LATE_Z) {
+            const uint32_t pg = (uint32_t)((seg0 >> 1) + tid + k * THREADS);
+#pragma unroll
+            for (int c = 0; c < D; ++c) box_muller(draw(v.seed, pg, stream, t, SLOT_NORMAL0 + c), z[k][c][0], z[k][c][1]);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             double zz[D];
