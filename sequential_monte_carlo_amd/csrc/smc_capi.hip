@@ -52,6 +52,7 @@ struct smc_filter_s {
     StepRec* d_recs = nullptr;
     double* h_pin = nullptr;                   // pinned host mirror [4][ntheta]: logZ | last_logmu | last_ess | ticket of the step API
     uint32_t seq = 0;                          // last ticket handed to a step-API launch
+    char* d_slab = nullptr;                    // ONE allocation behind x, C, the segment records, the per-filter scalars, params / streams / perm
     uint64_t* d_ms = nullptr;                  // scratch of the summaries of multi-segment filters (smc_summ_kernels.h) + [ntheta][QMAX] results
     uint64_t* d_brk = nullptr;                 // break points of the steps [v.brk_t0, v.brk_t0 + brk_count)
     uint32_t brk_cap = 0, brk_count = 0;
@@ -317,34 +318,39 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     TRY(hipEventCreate(&h->ev0));
     TRY(hipEventCreate(&h->ev1));
-    TRY(dalloc(&h->d_params, nt));
-    TRY(dalloc(&h->d_stream, nt));
-    TRY(dalloc(&h->d_perm, nt));
-    TRY(dalloc(&h->d_logZ_tmp, nt));
-    for (int b = 0; b < 2; ++b) {
-        TRY(dalloc(&v.x[b], np * (size_t)d));
-        TRY(dalloc(&v.C[b], np));
-        TRY(dalloc(&v.segk[b], ns));
-        TRY(dalloc(&v.segS[b], ns));
-        TRY(dalloc(&v.segS2hi[b], ns));
-        TRY(dalloc(&v.segS2lo[b], ns));
-        TRY(hipMemsetAsync(v.x[b], 0, np * (size_t)d * 8, h->stream));
-        TRY(hipMemsetAsync(v.C[b], 0, np * 8, h->stream));
-    }
-    if (flags & SMC_FLAG_ANCESTORS) TRY(dalloc(&v.anc, np));
-    TRY(dalloc(&v.logZ, nt));
-    TRY(dalloc(&v.last_logmu, nt));
-    TRY(dalloc(&v.last_ess, nt));
-    TRY(dalloc(&v.last_K, nt));
-    TRY(dalloc(&v.last_D, nt));
-    if (v.nseg_p2 > g.threads) {   // more segments than a workgroup has threads: the segment table is built once per step (k_table)
-        TRY(dalloc(&v.tabD, nt * (size_t)v.nseg_p2));
-        TRY(dalloc(&v.tabsh, nt * (size_t)v.nseg_p2));
+    {   // every array the handle always owns, in ONE device allocation (smc_create + smc_destroy of a 1024-particle filter: 0.63 ->
+        // ms with thirty-odd hipMalloc / hipFree calls - more than the filter's hundred steps take)
+        const bool gtab = v.nseg_p2 > g.threads;   // more segments than a workgroup has threads: the segment table is built once per step (k_table)
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_params = take(nt * sizeof(*h->d_params)), o_stream = take(nt * sizeof(*h->d_stream)), o_perm = take(nt * sizeof(*h->d_perm)),
+                     o_ztmp = take(nt * 8);
+        size_t o_x[2], o_C[2], o_k[2], o_S[2], o_hi[2], o_lo[2];
+        for (int b = 0; b < 2; ++b) {
+            o_x[b] = take(np * (size_t)d * 8); o_C[b] = take(np * 8);
+            o_k[b] = take(ns * 8); o_S[b] = take(ns * 8); o_hi[b] = take(ns * 8); o_lo[b] = take(ns * 8);
+        }
+        const size_t o_anc = (flags & SMC_FLAG_ANCESTORS) ? take(np * 4) : 0;
+        const size_t o_logZ = take(nt * 8), o_lm = take(nt * 8), o_es = take(nt * 8), o_K = take(nt * 8), o_D = take(nt * 8);
+        const size_t o_tD = gtab ? take(nt * (size_t)v.nseg_p2 * 8) : 0, o_tsh = gtab ? take(nt * (size_t)v.nseg_p2 * 4) : 0;
+        TRY(hipMalloc((void**)&h->d_slab, off));
+        TRY(hipMemsetAsync(h->d_slab, 0, off, h->stream));
+        char* base = h->d_slab;
+        h->d_params = (decltype(h->d_params))(base + o_params); h->d_stream = (decltype(h->d_stream))(base + o_stream);
+        h->d_perm = (decltype(h->d_perm))(base + o_perm); h->d_logZ_tmp = (double*)(base + o_ztmp);
+        for (int b = 0; b < 2; ++b) {
+            v.x[b] = (double*)(base + o_x[b]); v.C[b] = (uint64_t*)(base + o_C[b]);
+            v.segk[b] = (double*)(base + o_k[b]); v.segS[b] = (uint64_t*)(base + o_S[b]);
+            v.segS2hi[b] = (uint64_t*)(base + o_hi[b]); v.segS2lo[b] = (uint64_t*)(base + o_lo[b]);
+        }
+        if (flags & SMC_FLAG_ANCESTORS) v.anc = (decltype(v.anc))(base + o_anc);
+        v.logZ = (double*)(base + o_logZ); v.last_logmu = (double*)(base + o_lm); v.last_ess = (double*)(base + o_es);
+        v.last_K = (double*)(base + o_K); v.last_D = (uint64_t*)(base + o_D);
+        if (gtab) { v.tabD = (uint64_t*)(base + o_tD); v.tabsh = (int*)(base + o_tsh); }
     }
     TRY(hipHostMalloc((void**)&h->h_pin, 4 * nt * 8, hipHostMallocDefault));   // coherent, device-visible
     memset(h->h_pin, 0, 4 * nt * 8);
     v.host_out = h->h_pin;
-    TRY(hipMemsetAsync(v.logZ, 0, nt * 8, h->stream));
     std::vector<uint32_t> st(nt);
     for (size_t m = 0; m < nt; ++m) st[m] = (uint32_t)m;
     TRY(hipMemcpyAsync(h->d_stream, st.data(), nt * 4, hipMemcpyHostToDevice, h->stream));
@@ -456,9 +462,8 @@ extern "C" int smc_destroy(smc_handle h) {
     }
 #endif
     FilterView& v = h->v;
-    for (int b = 0; b < 2; ++b) {
-        (void)hipFree(v.x[b]); (void)hipFree(v.C[b]); (void)hipFree(v.segk[b]); (void)hipFree(v.segS[b]); (void)hipFree(v.segS2hi[b]); (void)hipFree(v.segS2lo[b]);
-    }
+    (void)v;
+    (void)hipFree(h->d_slab);   // x, C, the records, the per-filter scalars, the segment table, params / streams / perm
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
     if (h->h_pm_in) (void)hipHostFree(h->h_pm_in);
@@ -472,8 +477,7 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipFree(h->pm.prop); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip); (void)hipFree(h->pm.mask);
     if (h->d_brk) (void)hipFree(h->d_brk);
     if (h->d_ms) (void)hipFree(h->d_ms);
-    (void)hipFree(v.anc); (void)hipFree(v.logZ); (void)hipFree(v.last_logmu); (void)hipFree(v.last_ess); (void)hipFree(v.last_K); (void)hipFree(v.last_D); (void)hipFree(v.tabD); (void)hipFree(v.tabsh);
-    (void)hipFree(h->d_params); (void)hipFree(h->d_stream); (void)hipFree(h->d_perm); (void)hipFree(h->d_logZ_tmp); (void)hipFree(h->d_y);
+    (void)hipFree(h->d_y);
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
     (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m); (void)hipFree(h->d_pflags);
     if (h->h_perr) (void)hipHostFree(h->h_perr);
