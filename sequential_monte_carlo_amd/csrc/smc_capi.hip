@@ -320,7 +320,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
     TRY(hipEventCreate(&h->ev1));
     {   // every array the handle always owns, in ONE device allocation (smc_create + smc_destroy of a 1024-particle filter: 0.63 ->
         // 0.55 ms; thirty-odd hipMalloc / hipFree calls cost more than the filter's hundred steps)
-        const bool gtab = v.nseg_p2 > g.threads;   // more segments than a workgroup has threads: the segment table is built once per step (k_table)
+        const bool gtab = v.nseg_p2 > 2 * g.threads;   // more than twice as many segments as a workgroup has threads: the segment table is built once per step (k_table)
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t o_params = take(nt * sizeof(*h->d_params)), o_stream = take(nt * sizeof(*h->d_stream)), o_perm = take(nt * sizeof(*h->d_perm)),

@@ -416,13 +416,20 @@ __device__ __forceinline__ TableLds carve(char* smem, int nseg_p2) {
 struct TablePre {
     double k1;
     uint64_t S1, hi1, lo1;
+    double k2;      // RPT = 2 (two records per thread: filters with up to twice as many segments as threads): this thread's records are
+    uint64_t S2;    // 2 tid (k1, S1) and 2 tid + 1 (k2, S2)
 };
 // (VIEW: FilterView, or the same struct read in place from the kernel-argument segment - the persistent step kernel)
-template <int THREADS, class VIEW>
+template <int THREADS, class VIEW, int RPT = 1>
 __device__ __forceinline__ TablePre table_preload(const VIEW& v, int cur, int th, bool emit) {
-    TablePre p{-inf(), 0, 0, 0};
+    TablePre p{-inf(), 0, 0, 0, -inf(), 0};
     const int tid = smc_tid();
     const size_t base = (size_t)th * v.nseg;
+    if (RPT == 2) {   // records 2 tid and 2 tid + 1 (the table itself, when somebody needs it, is built by table_prologue from memory)
+        if (2 * tid < v.nseg) { p.k1 = v.segk[cur][base + 2 * tid]; p.S1 = v.segS[cur][base + 2 * tid]; }
+        if (2 * tid + 1 < v.nseg) { p.k2 = v.segk[cur][base + 2 * tid + 1]; p.S2 = v.segS[cur][base + 2 * tid + 1]; }
+        return p;
+    }
     if (v.nseg_p2 <= THREADS && tid < v.nseg) {
         p.k1 = v.segk[cur][base + tid];
         p.S1 = v.segS[cur][base + tid];
@@ -526,29 +533,41 @@ __device__ __forceinline__ uint64_t table_prologue(const VIEW& v, int cur, int t
 // one record per thread (nseg_p2 <= THREADS), the exponent maximum, one wave scan of the Q_b, the wave totals, and the NE + 1
 // values picked out of the lanes that hold them.  Two barriers (the full prologue: three, plus the table traffic).  The
 // numbers are the same integers table_prologue produces.  P0 = Dcum[lo-1] (0 for lo = 0), Dc[r] = Dcum[lo+r].
-template <int THREADS, int NE, class VIEW>
+template <int THREADS, int NE, class VIEW, int RPT = 1>
 __device__ __forceinline__ uint64_t window_prologue(const VIEW& v, uint64_t* scr, const TablePre& pre, int lo, uint64_t& P0,
                                                     uint64_t (&Dc)[NE], int (&shw)[NE], double& Kout) {
     constexpr int NW = THREADS / WAVE;
     constexpr int DEADK = (int)0x80000000;
     const int tid = smc_tid(), lane = tid & (WAVE - 1), wave = tid / WAVE;
-    const bool live = tid < v.nseg;
-    const int ki = (!live || pre.k1 == -inf()) ? DEADK : (int)pre.k1;
+    // RPT = 1: thread t holds the record of segment t; RPT = 2: of segments 2 t and 2 t + 1 (nseg <= 2 THREADS)
+    const bool live = RPT * tid < v.nseg, live2 = RPT == 2 && 2 * tid + 1 < v.nseg;
+    int ki = (!live || pre.k1 == -inf()) ? DEADK : (int)pre.k1;
+    if (RPT == 2) { const int k2 = (!live2 || pre.k2 == -inf()) ? DEADK : (int)pre.k2; ki = k2 > ki ? k2 : ki; }
     const int km = block_max_i32<THREADS>(ki, (int*)scr);            // barrier 1
     const double K = km == DEADK ? -inf() : (double)km;
     Kout = K;
-    int sh = 64;
-    uint64_t Q = 0;
+    int sh = 64, sh2 = 64;
+    uint64_t Q = 0, Q2 = 0;
     if (live) { sh = seg_shift(K, pre.k1, v.SH); Q = seg_Q(pre.S1, sh); }
-    const uint64_t incl = wave_incl_scan(Q, lane);
+    if (live2) { sh2 = seg_shift(K, pre.k2, v.SH); Q2 = seg_Q(pre.S2, sh2); }
+    const uint64_t incl = wave_incl_scan(Q + Q2, lane);   // inclusive (inside the wave) at this thread's LAST segment
     static_assert(2 * NE + 1 <= 8, "window words");
     uint64_t* wt = scr + NW;              // [NW] wave totals
     uint64_t* slot = scr + scr_words(THREADS, 1) - 16;   // the 8 window words (the same place for every NP: 4*NW + 0..7):
                                           // [0]: inclusive sum (inside its wave) at segment lo-1; [1..NE]: Q; [NE+1 .. 2NE]: sh
     if (lane == WAVE - 1) wt[wave] = incl;
-    if (tid == lo - 1) slot[0] = incl;
-    const int r = tid - lo;
-    if (r >= 0 && r < NE) { slot[1 + r] = Q; slot[1 + NE + r] = (uint64_t)(uint32_t)sh; }
+    if (RPT == 1) {
+        if (tid == lo - 1) slot[0] = incl;
+        const int r = tid - lo;
+        if (r >= 0 && r < NE) { slot[1 + r] = Q; slot[1 + NE + r] = (uint64_t)(uint32_t)sh; }
+    } else {
+        if (lo > 0 && tid == (lo - 1) >> 1) slot[0] = ((lo - 1) & 1) ? incl : incl - Q2;
+#pragma unroll
+        for (int r = 0; r < NE; ++r) {
+            const int e = lo + r;
+            if (tid == e >> 1) { slot[1 + r] = (e & 1) ? Q2 : Q; slot[1 + NE + r] = (uint64_t)(uint32_t)((e & 1) ? sh2 : sh); }
+        }
+    }
     __syncthreads();                                                 // barrier 2
     // totals of the waves: lanes 0..NW-1 of every wave scan them (DPP), Dtot and the offset of the wave holding segment lo-1
     uint64_t t = wt[lane & (NW - 1)];
@@ -559,7 +578,7 @@ __device__ __forceinline__ uint64_t window_prologue(const VIEW& v, uint64_t* scr
     const uint64_t Dtot = readlane_u64(t, NW - 1);
     uint64_t p0 = 0;
     if (lo > 0) {                                                    // workgroup-uniform
-        const int ws = __builtin_amdgcn_readfirstlane((lo - 1) / WAVE);
+        const int ws = __builtin_amdgcn_readfirstlane(((lo - 1) / RPT) / WAVE);
         const uint64_t before = ws > 0 ? readlane_u64(t, ws - 1) : 0;
         p0 = before + slot[0];
     }
@@ -840,9 +859,12 @@ __host__ __device__ inline size_t step_lds_bytes(int nseg_p2, int threads, int n
 // previous step's completion flags and made an agent-scope acquire before the call.
 // GTAB: the segment table comes from global memory (v.tabD, v.tabsh; k_table built it before this launch and emitted the previous
 // step): filters with more segments than the workgroup has threads.  No table in LDS, no emission here.
-template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS, bool PERSIST, class VIEW, bool GTAB = false>
+// RPT = 2: filters with more segments than threads, but at most twice as many: the window prologue with TWO records per thread
+// (no k_table launch yet; the rare full table in LDS as ever).
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS, bool PERSIST, class VIEW, bool GTAB = false, int RPT = 1>
 __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, int emit_prev, double yval, char* smem) {
     static_assert(!GTAB || (MULTI && !PERSIST), "global table: multi-segment launches");
+    static_assert(RPT == 1 || (RPT == 2 && MULTI && !GTAB && !PERSIST), "two records per thread: multi-segment launches");
     constexpr int D = model_dim<MODEL>::value;
     constexpr int SEG = 2 * NP * THREADS;
     constexpr int NQ = 2 * NP;   // particles per thread
@@ -881,7 +903,7 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         F0 = Fb[0];
         F1 = Fb[1];
     }
-    const TablePre tpre = (MULTI && !GTAB) ? table_preload<THREADS>(v, cur, th, emit_prev && sb == 0) : TablePre{-inf(), 0, 0, 0};
+    const TablePre tpre = (MULTI && !GTAB) ? table_preload<THREADS, VIEW, RPT>(v, cur, th, emit_prev && sb == 0) : TablePre{-inf(), 0, 0, 0, -inf(), 0};
     // (2) the 64-bit pick numbers of this thread's children
     uint64_t rr[NQ];
 #pragma unroll
@@ -984,7 +1006,7 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         const bool emitter = emit_prev && sb == 0;
         const bool emit_totals = emitter && emit_prev == 2;
         const int s_hi = spec_lo + NSTAGE - 1 < v.nseg - 1 ? spec_lo + NSTAGE - 1 : v.nseg - 1;
-        const bool use_fast = SPEC && (GTAB || ((!emitter || emit_totals) && v.nseg_p2 <= THREADS));      // workgroup-uniform
+        const bool use_fast = SPEC && (GTAB || ((!emitter || emit_totals) && v.nseg_p2 <= RPT * THREADS));      // workgroup-uniform
         uint64_t P0 = 0, Dc[NSTAGE];
         int shw[NSTAGE];
         if (GTAB) {   // the table exists: the total and, for the speculative window, its entries (nseg > THREADS >= NSTAGE)
@@ -997,10 +1019,10 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
             if (SYS) __syncthreads();   // (the step's uniform in LDS: the prologues' barriers otherwise)
         } else if (use_fast) {
             double Kw;
-            alive = window_prologue<THREADS, NSTAGE>(v, L.scr, tpre, spec_lo, P0, Dc, shw, Kw);
+            alive = window_prologue<THREADS, NSTAGE, VIEW, RPT>(v, L.scr, tpre, spec_lo, P0, Dc, shw, Kw);
             if (emit_totals && tid == 0) emit_from_totals(v, th, Kw, alive, t == 1u, t - 1u);
         } else {
-            alive = table_prologue<THREADS>(v, cur, th, L, emitter, t == 1u, t - 1u, &tpre);
+            alive = table_prologue<THREADS>(v, cur, th, L, emitter, t == 1u, t - 1u, RPT == 1 ? &tpre : nullptr);
         }
         SMC_STAMP(v, 1);
         SMC_PRIO(1);
@@ -1021,7 +1043,7 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
         bool fast = false;
         if (use_fast) {
             fast = (spec_lo == 0 || P0 <= Tfirst) && Tlast < Dc[s_hi - spec_lo];
-            if (!fast && !GTAB) alive = table_prologue<THREADS>(v, cur, th, L, false, false, 0u, &tpre);   // rare: very uneven weights
+            if (!fast && !GTAB) alive = table_prologue<THREADS>(v, cur, th, L, false, false, 0u, RPT == 1 ? &tpre : nullptr);   // rare: very uneven weights
         }
         int b_lo = 0, b_hi = 0;
         if (fast || (SPEC && !use_fast && (spec_lo == 0 || L.Dcum[spec_lo - 1] <= Tfirst) && Tlast < L.Dcum[s_hi])) {
@@ -1286,10 +1308,10 @@ __device__ __forceinline__ void step_body(const VIEW& v, int cur, uint32_t t, in
     SMC_STAMP(v, 7);
 }
 
-template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false, bool GTAB = false>
+template <int MODEL, int THREADS, int NP, bool MULTI, bool SYS = false, bool GTAB = false, int RPT = 1>
 __global__ __launch_bounds__(THREADS) void k_step(FilterView v, int cur, uint32_t t, int emit_prev, double yval) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    step_body<MODEL, THREADS, NP, MULTI, SYS, false, FilterView, GTAB>(v, cur, t, emit_prev, yval, smem);
+    step_body<MODEL, THREADS, NP, MULTI, SYS, false, FilterView, GTAB, RPT>(v, cur, t, emit_prev, yval, smem);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -40,6 +40,13 @@ static hipError_t step_sys_t(const FilterView& v, int cur, uint32_t t, int emit_
         return hipGetLastError();
     }
     const size_t lds = step_lds_bytes(v.nseg_p2, THREADS, NP, v.nseg > 1);
+    if (v.nseg_p2 > THREADS) {   // up to twice as many segments as threads: the window prologue with two records per thread
+        static bool raised[16] = {};
+        hipError_t e = raise_lds_limit(k_step<SMC_MODEL, THREADS, NP, true, SYS, false, 2>, lds, raised);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_step<SMC_MODEL, THREADS, NP, true, SYS, false, 2>), dim3(v.nseg, v.ntheta), dim3(THREADS), lds, s, v, cur, t, emit_prev, y);
+        return hipGetLastError();
+    }
     {
         static bool raised[2][16] = {};   // per instantiation, variant and device
         hipError_t e = v.nseg > 1 ? raise_lds_limit(k_step<SMC_MODEL, THREADS, NP, true, SYS>, lds, raised[1])

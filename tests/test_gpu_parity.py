@@ -477,15 +477,19 @@ def test_many_segments_per_thread_bit_exact(L, ob):
 
 
 def test_global_segment_table_paths(L, ob):
-    """Filters with more segments than a workgroup has threads take the segment table from global memory (k_table builds it once
-    per step, k_step<..., GTAB> reads its window and the total): without traces (the previous step emitted from the totals), with
+    """Filters with more segments than a workgroup has threads: up to twice as many, the window prologue holds two records per
+    thread; beyond, the segment table comes from global memory (k_table builds it once per step, k_step<..., GTAB> reads its window
+    and the total).  Both: without traces (the previous step emitted from the totals), with
     them, batches with distinct parameters, three state coordinates, ragged sizes, wildly uneven weights (targets outside the
     speculative window: the searches walk the GLOBAL table), the systematic resampler, the step API with a permutation in between -
     bit-exact against the oracle every way."""
     # (model, raw, n, seg, ntheta, flags)
     UC = RAW[3]
+    # up to twice as many segments as threads: the window prologue with two records per thread (the first five cases); beyond: k_table
     cases = ((1, LG, 40000, 256, 2, 0), (3, UC, 33000, 256, 1, 0), (1, [0.9, 1.0, 1.0, 1e-6, 0.0, 4.0], 60000, 256, 1, 0),
-             (1, LG, 300 * 512 - 5, 512, 1, L.FLAG_SYSTEMATIC), (2, SV, 1030 * 1024, 1024, 1, 0))
+             (1, LG, 300 * 512 - 5, 512, 1, L.FLAG_SYSTEMATIC), (2, SV, 700 * 1024, 1024, 1, 0),
+             (1, LG, 70000, 256, 2, 0), (3, UC, 67000, 256, 1, 0), (1, [0.9, 1.0, 1.0, 1e-6, 0.0, 4.0], 90000, 256, 1, 0),
+             (1, LG, 600 * 512 - 5, 512, 1, L.FLAG_SYSTEMATIC), (2, SV, 1030 * 1024, 1024, 1, 0))
     for model, raw, n, seg, nth, flags in cases:
         T = 6 if n < 500000 else 3
         _, y = ob.simulate(model, RAW[model], T, 11)
@@ -506,25 +510,25 @@ def test_global_segment_table_paths(L, ob):
             assert bits([z0[th]])[0] == bits([z])[0] and same(lm[:, th], olm) and same(es[:, th], oes), (model, n, seg)
             assert same(x0[:, th], ox) and same(w0[th], ow) and np.array_equal(a0[th], oa), (model, n, seg)
         h.close()
-    # the step API: init, steps, a permutation of the filter slots, more steps
-    n, seg = 50000, 256
-    _, y = ob.simulate(1, LG, 8, 4)
-    h = L.Handle(1, 2, n, seg=seg, seed=21)
-    h.set_params(np.tile(LG, (2, 1)))
-    fs = [ob.Filter(1, LG, n, seg=seg, seed=21, stream=th) for th in range(2)]
-    assert same(h.init(float(y[0])), [f.bootstrap_filter(float(y[0])) for f in fs])
-    for t in range(1, 8):
-        if t == 4:
-            h.permute(np.array([1, 1], dtype=np.int32))     # slot 0 becomes a value copy of slot 1 (keeps its own stream)
-            fs[0].copy_state_from(fs[1])
-        lm, es = h.step(float(y[t]))
-        ref = [f.step(float(y[t])) for f in fs]
-        assert same(lm, [r[0] for r in ref]) and same(es, [r[1] for r in ref]), t
-    x, w, _ = h.state(want_anc=False)
-    for th in range(2):
-        ox, ow, _, _ = fs[th].state()
-        assert same(x[:, th], ox) and same(w[th], ow)
-    h.close()
+    # the step API: init, steps, a permutation of the filter slots, more steps (two records per thread; k_table)
+    for n, seg in ((50000, 256), (80000, 256)):
+        _, y = ob.simulate(1, LG, 8, 4)
+        h = L.Handle(1, 2, n, seg=seg, seed=21)
+        h.set_params(np.tile(LG, (2, 1)))
+        fs = [ob.Filter(1, LG, n, seg=seg, seed=21, stream=th) for th in range(2)]
+        assert same(h.init(float(y[0])), [f.bootstrap_filter(float(y[0])) for f in fs])
+        for t in range(1, 8):
+            if t == 4:
+                h.permute(np.array([1, 1], dtype=np.int32))     # slot 0 becomes a value copy of slot 1 (keeps its own stream)
+                fs[0].copy_state_from(fs[1])
+            lm, es = h.step(float(y[t]))
+            ref = [f.step(float(y[t])) for f in fs]
+            assert same(lm, [r[0] for r in ref]) and same(es, [r[1] for r in ref]), t
+        x, w, _ = h.state(want_anc=False)
+        for th in range(2):
+            ox, ow, _, _ = fs[th].state()
+            assert same(x[:, th], ox) and same(w[th], ow)
+        h.close()
 
 
 def test_large_filters_beyond_2_pow_20(L):
