@@ -15,6 +15,7 @@
 #include <string>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 using namespace smc;
@@ -52,6 +53,7 @@ struct smc_filter_s {
     StepRec* d_recs = nullptr;
     double* h_pin = nullptr;                   // pinned host mirror [4][ntheta]: logZ | last_logmu | last_ess | ticket of the step API
     uint32_t seq = 0;                          // last ticket handed to a step-API launch
+    size_t slab_bytes = 0, pin_bytes = 0;
     char* d_slab = nullptr;                    // ONE allocation behind x, C, the segment records, the per-filter scalars, params / streams / perm
     uint64_t* d_ms = nullptr;                  // scratch of the summaries of multi-segment filters (smc_summ_kernels.h) + [ntheta][QMAX] results
     uint64_t* d_brk = nullptr;                 // break points of the steps [v.brk_t0, v.brk_t0 + brk_count)
@@ -257,6 +259,46 @@ static hipError_t dalloc(T** p, size_t count) {
     return hipMalloc((void**)p, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
 }
 
+// What every handle needs and the runtime is slow to give back (hipFree, hipStreamDestroy and hipHostFree made smc_destroy cost
+// 0.48 ms - twice the hundred steps of a 1024-particle filter): the slab, the stream, the two events and the pinned mirror of a
+// destroyed handle are kept (a few, bounded in bytes) and handed to the next smc_create that fits them.
+namespace {
+struct Bundle {
+    int device = -1;
+    char* slab = nullptr; size_t slab_bytes = 0;
+    double* pin = nullptr; size_t pin_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+struct BundleCache {
+    std::mutex mu;
+    std::vector<Bundle> free_list;
+    size_t bytes = 0;
+    static constexpr size_t MAX_BYTES = (size_t)512 << 20, MAX_COUNT = 8;
+    bool take(int device, size_t slab_bytes, size_t pin_bytes, Bundle& out) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < free_list.size(); ++i) {
+            const Bundle& b = free_list[i];
+            if (b.device == device && b.slab_bytes >= slab_bytes && b.slab_bytes <= 2 * slab_bytes + 4096 && b.pin_bytes >= pin_bytes) {
+                out = b;
+                bytes -= b.slab_bytes;
+                free_list.erase(free_list.begin() + (long)i);
+                return true;
+            }
+        }
+        return false;
+    }
+    bool give(const Bundle& b) {
+        std::lock_guard<std::mutex> g(mu);
+        if (free_list.size() >= MAX_COUNT || bytes + b.slab_bytes > MAX_BYTES) return false;
+        free_list.push_back(b);
+        bytes += b.slab_bytes;
+        return true;
+    }
+};
+BundleCache& bundle_cache() { static BundleCache* c = new BundleCache(); return *c; }   // (never destroyed: no runtime calls at exit)
+}  // namespace
+
 extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, uint64_t seed, int device, uint32_t flags,
                           smc_handle* out) {
     if (!out) return fail(SMC_EINVAL, "smc_create: out is NULL");
@@ -315,9 +357,7 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
             return fail(SMC_ENOMEM, "smc_create: " #expr ": " + m); \
         }                                               \
     } while (0)
-    TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    TRY(hipEventCreate(&h->ev0));
-    TRY(hipEventCreate(&h->ev1));
+    Bundle bun;   // filled from the cache once the sizes are known (below); fresh resources otherwise
     {   // every array the handle always owns, in ONE device allocation (smc_create + smc_destroy of a 1024-particle filter: 0.63 ->
         // 0.55 ms; thirty-odd hipMalloc / hipFree calls cost more than the filter's hundred steps)
         const bool gtab = v.nseg_p2 > 2 * g.threads;   // more than twice as many segments as a workgroup has threads: the segment table is built once per step (k_table)
@@ -333,7 +373,16 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
         const size_t o_anc = (flags & SMC_FLAG_ANCESTORS) ? take(np * 4) : 0;
         const size_t o_logZ = take(nt * 8), o_lm = take(nt * 8), o_es = take(nt * 8), o_K = take(nt * 8), o_D = take(nt * 8);
         const size_t o_tD = gtab ? take(nt * (size_t)v.nseg_p2 * 8) : 0, o_tsh = gtab ? take(nt * (size_t)v.nseg_p2 * 4) : 0;
-        TRY(hipMalloc((void**)&h->d_slab, off));
+        h->slab_bytes = off;
+        if (bundle_cache().take(device, off, 4 * nt * 8, bun)) {
+            h->d_slab = bun.slab; h->slab_bytes = bun.slab_bytes; h->stream = bun.stream; h->ev0 = bun.ev0; h->ev1 = bun.ev1;
+            h->h_pin = bun.pin; h->pin_bytes = bun.pin_bytes;
+        } else {
+            TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+            TRY(hipEventCreate(&h->ev0));
+            TRY(hipEventCreate(&h->ev1));
+            TRY(hipMalloc((void**)&h->d_slab, off));
+        }
         TRY(hipMemsetAsync(h->d_slab, 0, off, h->stream));
         char* base = h->d_slab;
         h->d_params = (decltype(h->d_params))(base + o_params); h->d_stream = (decltype(h->d_stream))(base + o_stream);
@@ -348,7 +397,10 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
         v.last_K = (double*)(base + o_K); v.last_D = (uint64_t*)(base + o_D);
         if (gtab) { v.tabD = (uint64_t*)(base + o_tD); v.tabsh = (int*)(base + o_tsh); }
     }
-    TRY(hipHostMalloc((void**)&h->h_pin, 4 * nt * 8, hipHostMallocDefault));   // coherent, device-visible
+    if (!h->h_pin) {
+        TRY(hipHostMalloc((void**)&h->h_pin, 4 * nt * 8, hipHostMallocDefault));   // coherent, device-visible
+        h->pin_bytes = 4 * nt * 8;
+    }
     memset(h->h_pin, 0, 4 * nt * 8);
     v.host_out = h->h_pin;
     std::vector<uint32_t> st(nt);
@@ -461,8 +513,14 @@ extern "C" int smc_destroy(smc_handle h) {
         (void)hipFree(h->v.dbg);
     }
 #endif
-    (void)hipFree(h->d_slab);   // x, C, the records, the per-filter scalars, the segment table, params / streams / perm
-    if (h->h_pin) (void)hipHostFree(h->h_pin);
+    Bundle bun;
+    bun.device = h->device; bun.slab = h->d_slab; bun.slab_bytes = h->slab_bytes; bun.pin = h->h_pin; bun.pin_bytes = h->pin_bytes;
+    bun.stream = h->stream; bun.ev0 = h->ev0; bun.ev1 = h->ev1;
+    const bool kept = h->d_slab && h->h_pin && h->stream && h->ev0 && h->ev1 && bundle_cache().give(bun);   // (the stream is idle: synchronised above)
+    if (!kept) {
+        (void)hipFree(h->d_slab);   // x, C, the records, the per-filter scalars, the segment table, params / streams / perm
+        if (h->h_pin) (void)hipHostFree(h->h_pin);
+    }
     if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
     if (h->h_pm_in) (void)hipHostFree(h->h_pm_in);
     if (h->h_perm) (void)hipHostFree(h->h_perm);
@@ -479,9 +537,11 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
     (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m); (void)hipFree(h->d_pflags);
     if (h->h_perr) (void)hipHostFree(h->h_perr);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (!kept) {
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
     delete h;
     return SMC_OK;
 }
