@@ -269,6 +269,9 @@ struct Bundle {
     double* pin = nullptr; size_t pin_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* d_y = nullptr; int64_t ycap = 0;          // the series buffer and the per-step records of the whole-series calls
+    void* d_recs = nullptr; size_t rec_bytes = 0;     // (whatever the destroyed handle had grown them to)
+    void* h_params = nullptr; size_t params_bytes = 0;   // pinned twin of the parameter rows
 };
 struct BundleCache {
     std::mutex mu;
@@ -377,6 +380,10 @@ extern "C" int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, u
         if (bundle_cache().take(device, off, 4 * nt * 8, bun)) {
             h->d_slab = bun.slab; h->slab_bytes = bun.slab_bytes; h->stream = bun.stream; h->ev0 = bun.ev0; h->ev1 = bun.ev1;
             h->h_pin = bun.pin; h->pin_bytes = bun.pin_bytes;
+            h->d_y = bun.d_y; h->ycap = bun.ycap;
+            h->d_recs = (decltype(h->d_recs))bun.d_recs; h->reccap = (int64_t)(bun.rec_bytes / (nt * sizeof(*h->d_recs)));
+            if (bun.params_bytes >= nt * sizeof(Params)) h->h_params = (Params*)bun.h_params;
+            else if (bun.h_params) (void)hipHostFree(bun.h_params);
         } else {
             TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
             TRY(hipEventCreate(&h->ev0));
@@ -516,6 +523,8 @@ extern "C" int smc_destroy(smc_handle h) {
     Bundle bun;
     bun.device = h->device; bun.slab = h->d_slab; bun.slab_bytes = h->slab_bytes; bun.pin = h->h_pin; bun.pin_bytes = h->pin_bytes;
     bun.stream = h->stream; bun.ev0 = h->ev0; bun.ev1 = h->ev1;
+    bun.d_y = h->d_y; bun.ycap = h->ycap; bun.d_recs = h->d_recs; bun.rec_bytes = (size_t)h->reccap * (size_t)h->v.ntheta * sizeof(*h->d_recs);
+    bun.h_params = h->h_params; bun.params_bytes = h->h_params ? (size_t)h->v.ntheta * sizeof(Params) : 0;
     const bool kept = h->d_slab && h->h_pin && h->stream && h->ev0 && h->ev1 && bundle_cache().give(bun);   // (the stream is idle: synchronised above)
     if (!kept) {
         (void)hipFree(h->d_slab);   // x, C, the records, the per-filter scalars, the segment table, params / streams / perm
@@ -524,7 +533,7 @@ extern "C" int smc_destroy(smc_handle h) {
     if (h->h_pm_out) (void)hipHostFree(h->h_pm_out);
     if (h->h_pm_in) (void)hipHostFree(h->h_pm_in);
     if (h->h_perm) (void)hipHostFree(h->h_perm);
-    if (h->h_params) (void)hipHostFree(h->h_params);
+    if (h->h_params && !kept) (void)hipHostFree(h->h_params);
     (void)hipFree(h->d_skip); (void)hipFree(h->d_order);
     if (h->h_win) (void)hipHostFree(h->h_win);
     if (h->h_once) (void)hipHostFree(h->h_once);
@@ -533,8 +542,8 @@ extern "C" int smc_destroy(smc_handle h) {
     (void)hipFree(h->pm.prop); (void)hipFree(h->pm.lp); (void)hipFree(h->pm.skip); (void)hipFree(h->pm.mask);
     if (h->d_brk) (void)hipFree(h->d_brk);
     if (h->d_ms) (void)hipFree(h->d_ms);
-    (void)hipFree(h->d_y);
-    (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); (void)hipFree(h->d_recs);
+    if (!kept) (void)hipFree(h->d_y);
+    (void)hipFree(h->d_tr_logmu); (void)hipFree(h->d_tr_ess); (void)hipFree(h->d_wdense); if (!kept) (void)hipFree(h->d_recs);
     (void)hipFree(h->d_sum_q); (void)hipFree(h->d_sum_m); (void)hipFree(h->d_pflags);
     if (h->h_perr) (void)hipHostFree(h->h_perr);
     if (!kept) {
