@@ -52,6 +52,9 @@ typedef struct smc_filter_s* smc_handle;
  * choice keeps segments of 2048 up to 2^25 particles).  Filter m uses Philox stream id m until smc_set_streams says otherwise. */
 int smc_create(int model_id, int64_t n_theta, int64_t n_x, int seg, uint64_t seed, int device, uint32_t flags,
                smc_handle* out);
+/* waits for the handle's stream, then releases it.  The device slab, the stream, the events and the pinned mirrors of up to 8
+ * destroyed handles (512 MB of device memory at most) are kept for the next smc_create that fits them: creating and destroying
+ * a handle per call costs 0.02 ms instead of 0.6 ms. */
 int smc_destroy(smc_handle h);
 
 /* smc.model(theta[m]) for every m (src/smc_samplers.jl:120,178,227,293,330): raw parameter rows. */
