@@ -396,6 +396,85 @@ __global__ __launch_bounds__(THREADS) void k_resample_cdf(const double* w, int64
     if (tid == 0) *status = 0;
 }
 
+// The same inclusive sums for a long vector, grid-wide (every cross-workgroup combination an integer sum or a maximum: the same
+// bits as the single workgroup): the maximum; the sum of every workgroup's contiguous chunk; their exclusive scan (one workgroup);
+// the chunk's inclusive sums on top of its offset.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rs_max(const double* w, int64_t n, unsigned long long* mbits) {
+    __shared__ double red[THREADS / WAVE];
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * THREADS) { const double x = w[i]; m = x > m ? x : m; }
+    m = block_max<THREADS>(m, red);
+    if (threadIdx.x == 0) atomicMax(mbits, (unsigned long long)d2bits(m));   // (non-negative doubles order like their bits; +inf included)
+}
+__device__ __forceinline__ uint64_t rs_q(double w, double m, double scale) {
+    const double r = w / m;
+    return (r == r && r > 0.0) ? (uint64_t)rne_pos(r * scale) : 0;
+}
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rs_chunk_sums(const double* w, int64_t n, int K, const unsigned long long* mbits, int64_t chunk, uint64_t* bs) {
+    __shared__ uint64_t wt[THREADS / WAVE];
+    const double m = bits2d(*mbits);
+    if (!(m > 0.0) || m == inf()) return;
+    const double scale = pow2i(K);
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    uint64_t s = 0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += THREADS) s += rs_q(w[i], m, scale);
+    s = wave_sum(s);
+    if ((threadIdx.x & (WAVE - 1)) == 0) wt[threadIdx.x / WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t t = 0; for (int k = 0; k < THREADS / WAVE; ++k) t += wt[k]; bs[blockIdx.x] = t; }
+}
+// one workgroup: exclusive scan of the nb chunk sums in place; status = -2 for an unusable maximum
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rs_scan_chunks(const unsigned long long* mbits, int nb, uint64_t* bs, int* status) {
+    constexpr int NW = THREADS / WAVE;
+    __shared__ uint64_t wt[NW];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const double m = bits2d(*mbits);
+    if (!(m > 0.0) || m == inf()) { if (tid == 0) *status = -2; return; }
+    uint64_t carry = 0;
+    for (int base = 0; base < nb; base += THREADS) {
+        const int i = base + tid;
+        const uint64_t v = i < nb ? bs[i] : 0;
+        const uint64_t incl = wave_incl_scan(v, lane);
+        if (lane == WAVE - 1) wt[wave] = incl;
+        __syncthreads();
+        uint64_t off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { off += (k < wave) ? wt[k] : 0; tot += wt[k]; }
+        if (i < nb) bs[i] = carry + off + incl - v;
+        carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *status = 0;
+}
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_rs_write(const double* w, int64_t n, int K, const unsigned long long* mbits, int64_t chunk, const uint64_t* bs,
+                                                      uint64_t* C) {
+    constexpr int NW = THREADS / WAVE;
+    __shared__ uint64_t wt[NW];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const double m = bits2d(*mbits);
+    if (!(m > 0.0) || m == inf()) return;
+    const double scale = pow2i(K);
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    uint64_t carry = bs[blockIdx.x];
+    for (int64_t base = i0; base < i1; base += THREADS) {
+        const int64_t i = base + tid;
+        const uint64_t q = i < i1 ? rs_q(w[i], m, scale) : 0;
+        const uint64_t incl = wave_incl_scan(q, lane);
+        if (lane == WAVE - 1) wt[wave] = incl;
+        __syncthreads();
+        uint64_t off = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { off += (k < wave) ? wt[k] : 0; tot += wt[k]; }
+        if (i < i1) C[i] = carry + off + incl;
+        carry += tot;
+        __syncthreads();
+    }
+}
+
 __global__ void k_resample_draw(const uint64_t* C, int64_t n, int64_t ndraw, uint64_t seed, uint32_t stream, uint32_t t,
                                 int32_t* a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

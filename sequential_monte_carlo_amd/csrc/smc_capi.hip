@@ -1523,7 +1523,23 @@ extern "C" int smc_resample(const double* w, int64_t n, int64_t ndraw, uint64_t 
     HIPCHK(d_a.alloc((size_t)ndraw * 4));
     HIPCHK(d_st.alloc(4));
     HIPCHK(hipMemcpyAsync(d_w.p, w, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((k_resample_cdf<1024>), dim3(1), dim3(1024), 0, st, d_w.as<double>(), n, fix_bits_for(n), d_C.as<uint64_t>(), d_st.as<int>());
+    if (n <= 65536) {
+        hipLaunchKernelGGL((k_resample_cdf<1024>), dim3(1), dim3(1024), 0, st, d_w.as<double>(), n, fix_bits_for(n), d_C.as<uint64_t>(), d_st.as<int>());
+    } else {   // a whole cloud's weights: the inclusive sums grid-wide (the same integers)
+        constexpr int TH = 256;
+        int nb = (int)((n + 4 * TH - 1) / (4 * TH));
+        nb = nb > 2048 ? 2048 : nb;
+        const int64_t chunk = ((n + nb - 1) / nb + TH - 1) / TH * TH;   // contiguous, a multiple of the workgroup
+        nb = (int)((n + chunk - 1) / chunk);
+        DevBuf d_bs(4);
+        HIPCHK(d_bs.alloc(((size_t)nb + 1) * 8));
+        unsigned long long* mbits = d_bs.as<unsigned long long>() + nb;
+        HIPCHK(hipMemsetAsync(mbits, 0, 8, st));
+        hipLaunchKernelGGL((k_rs_max<TH>), dim3((unsigned)nb), dim3(TH), 0, st, d_w.as<double>(), n, mbits);
+        hipLaunchKernelGGL((k_rs_chunk_sums<TH>), dim3((unsigned)nb), dim3(TH), 0, st, d_w.as<double>(), n, fix_bits_for(n), mbits, chunk, d_bs.as<uint64_t>());
+        hipLaunchKernelGGL((k_rs_scan_chunks<1024>), dim3(1), dim3(1024), 0, st, mbits, nb, d_bs.as<uint64_t>(), d_st.as<int>());
+        hipLaunchKernelGGL((k_rs_write<TH>), dim3((unsigned)nb), dim3(TH), 0, st, d_w.as<double>(), n, fix_bits_for(n), mbits, chunk, d_bs.as<uint64_t>(), d_C.as<uint64_t>());
+    }
     HIPCHK(hipGetLastError());
     int status = 0;
     HIPCHK(hipMemcpyAsync(&status, d_st.p, 4, hipMemcpyDeviceToHost, st));

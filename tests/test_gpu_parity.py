@@ -169,7 +169,7 @@ def test_step_api_matches_whole_series(L, ob):
 
 def test_standalone_normalize_resample(L, ob):
     rng = np.random.default_rng(11)
-    for n in (1, 2, 63, 512, 4096, 16384, 16385, 100000, 1 << 20):      # > 16384: the three-pass grid-wide kernels
+    for n in (1, 2, 63, 512, 4096, 16384, 16385, 65536, 65537, 100000, 1 << 20, (1 << 21) + 5):      # > 16384 (normalize), > 65536 (resample): the grid-wide kernels
         logw = rng.normal(size=n) * 5 - 100
         if n > 10:
             logw[3] = -np.inf
