@@ -136,7 +136,7 @@ hipError_t launch_resident<SMC_MODEL>(const FilterView& v, int T, StepRec* recs,
     case 512: return resident_t<256, 1>(v, T, recs, s);
     case 1024: return np == 1 ? resident_t<512, 1>(v, T, recs, s) : np == 4 ? resident_t<128, 4>(v, T, recs, s) : resident_t<256, 2>(v, T, recs, s);
     case 2048: return np == 1 ? resident_t<1024, 1>(v, T, recs, s) : np == 4 ? resident_t<256, 4>(v, T, recs, s) : resident_t<512, 2>(v, T, recs, s);
-    case 4096: return np == 2 ? resident_t<1024, 2>(v, T, recs, s) : resident_t<512, 4>(v, T, recs, s);   // 1024 threads spill
+    case 4096: return np == 4 ? resident_t<512, 4>(v, T, recs, s) : resident_t<1024, 2>(v, T, recs, s);   // (1024 x 2 spills a little and still wins: +5-10 %, scripts/dbg/res4096.py)
     case 8192:
         if constexpr (model_dim<SMC_MODEL>::value == 1) return resident_t<1024, 4>(v, T, recs, s);
         else return hipErrorInvalidValue;
@@ -177,7 +177,7 @@ hipError_t launch_window<SMC_MODEL>(const FilterView& v, int T, StepRec* recs, i
     case 512: return window_t<256, 1>(v, T, recs, t0, bin, bout, win, s);
     case 1024: return np == 1 ? window_t<512, 1>(v, T, recs, t0, bin, bout, win, s) : window_t<256, 2>(v, T, recs, t0, bin, bout, win, s);
     case 2048: return window_t<512, 2>(v, T, recs, t0, bin, bout, win, s);
-    case 4096: return window_t<512, 4>(v, T, recs, t0, bin, bout, win, s);
+    case 4096: return np == 4 ? window_t<512, 4>(v, T, recs, t0, bin, bout, win, s) : window_t<1024, 2>(v, T, recs, t0, bin, bout, win, s);
     case 8192:
         if constexpr (model_dim<SMC_MODEL>::value == 1) return window_t<1024, 4>(v, T, recs, t0, bin, bout, win, s);
         else return hipErrorInvalidValue;
