@@ -120,12 +120,13 @@ static hipError_t window_t(const FilterView& v, int T, StepRec* recs, int t0, in
 }
 
 // threads / particle pairs per thread of the LDS-resident kernels for a segment length.  Measured (scripts/res_tune.py,
-// scripts/prof_c2.py): with few filters in flight (<= 4 waves per SIMD at two pairs per thread) every model runs faster with
-// one pair per thread (twice the waves: 512 UCSV filters 2.05 -> 1.81 ms); large batches prefer two pairs per thread.  SMC_RES_NP (1, 2 or 4) overrides
-// the choice for tuning runs; results do not depend on it (tests/test_gpu_parity.py::test_launch_geometry_knobs).
+// scripts/prof_c2.py, scripts/dbg/res1024.py): with at most two workgroups per CU in flight (n_theta <= 512) every model runs faster
+// with one pair per thread (twice the waves: 512 UCSV filters 2.05 -> 1.81 ms); beyond, workgroups of half the size with two
+// pairs per thread pack the CUs without a ragged last round (576 .. 768 filters: +30 % LG, +11 % UCSV; 1024: +8 %).  SMC_RES_NP
+// (1, 2 or 4) overrides the choice for tuning runs; results do not depend on it (tests/test_gpu_parity.py::test_launch_geometry_knobs).
 static int resident_np(const FilterView& v) {
     const char* e = getenv("SMC_RES_NP");
-    return e ? atoi(e) : (v.seg == 1024 && v.ntheta <= 1024) ? 1 : 0;
+    return e ? atoi(e) : (v.seg == 1024 && v.ntheta <= 512) ? 1 : 0;
 }
 
 template <>
